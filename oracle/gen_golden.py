@@ -1,0 +1,247 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own functions (TEST INFRASTRUCTURE).
+
+Runs only in the build container (needs /root/reference).  Recipe = SURVEY.md section 8(c):
+third-party modules that are absent offline (diffusers, wandb, h5py, torchvision, cv2) are
+MagicMock'ed, the reference's `datasets/` namespace dir is pre-registered so the installed
+HuggingFace `datasets` does not shadow it, then `optimize_token` is imported first.
+
+The fixtures hold DATA only: seeds/shapes of the inputs (inputs are regenerated with
+`oracle.fixtures.seeded`), and the reference's outputs.  Nothing of the reference's source
+text is stored.
+
+    python -m oracle.gen_golden          # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for m in ["diffusers", "wandb", "h5py", "torchvision", "torchvision.transforms",
+              "torchvision.transforms.functional", "cv2"]:
+        sys.modules[m] = MagicMock()
+    ds = types.ModuleType("datasets")
+    ds.__path__ = [os.path.join(REF, "datasets")]
+    sys.modules["datasets"] = ds
+    from unsupervised_keypoints import optimize_token  # noqa: F401  (import order matters)
+    from unsupervised_keypoints import ptp_utils, optimize, eval as ref_eval, invertable_transform
+    return optimize_token, ptp_utils, optimize, ref_eval, invertable_transform
+
+
+# --- a stand-in module tree with the diffusers==0.8.0 CrossAttention attribute layout ----
+class CrossAttention(torch.nn.Module):          # class name is what the reference matches on
+    def __init__(self, query_dim, context_dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.scale = (query_dim // heads) ** -0.5
+        self.to_q = torch.nn.Linear(query_dim, query_dim, bias=False)
+        self.to_k = torch.nn.Linear(context_dim, query_dim, bias=False)
+        self.to_v = torch.nn.Linear(context_dim, query_dim, bias=False)
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(query_dim, query_dim), torch.nn.Dropout(0.0)])
+
+    def reshape_heads_to_batch_dim(self, t):
+        b, n, c = t.shape
+        h = self.heads
+        return t.reshape(b, n, h, c // h).permute(0, 2, 1, 3).reshape(b * h, n, c // h)
+
+    def reshape_batch_dim_to_heads(self, t):
+        bh, n, d = t.shape
+        h = self.heads
+        return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, d * h)
+
+
+class Net(torch.nn.Module):
+    def __init__(self, mods):
+        super().__init__()
+        self.up_blocks = torch.nn.ModuleList(mods)
+
+
+def main():
+    from oracle.fixtures import seeded, HOOK_CASES, STACK_CASE, load_weights_into, SEL_CASE, E2E_CASE
+    optimize_token, ptp_utils, optimize, ref_eval, inv = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+
+    # ---------------- G1: the hook on one module -------------------------------------
+    g1 = {}
+    for name, c in HOOK_CASES.items():
+        mod = CrossAttention(c["C"], c["ctx_dim"], c["heads"])
+        load_weights_into(mod, c["seed"])
+        mod_self = CrossAttention(c["C"], c["C"], c["heads"])      # attn1-style (context=None)
+        load_weights_into(mod_self, c["seed"] + 1000)
+        net = Net([mod, mod_self])
+        ctrl = ptp_utils.AttentionStore()
+        ptp_utils.register_attention_control(net, ctrl, feature_upsample_res=c["R"])
+        x = seeded((c["B"], c["s"] * c["s"], c["C"]), c["seed"] + 100)
+        ctx = seeded((c["B"], c["T"], c["ctx_dim"]), c["seed"] + 200)
+        with torch.no_grad():
+            out = mod.forward(x, context=ctx)
+        p_up = ctrl.step_store["attn"][0]
+        assert ctrl.num_att_layers == 2 and len(ctrl.step_store["attn"]) == 1
+        if c["full"]:
+            g1[name + "/p_up"] = p_up.numpy()
+            g1[name + "/out"] = out.numpy()
+        else:  # SD-shape case: strided sample + sums
+            g1[name + "/p_up_strided"] = p_up.reshape(-1)[:: c["stride"]].numpy()
+            g1[name + "/out_strided"] = out.reshape(-1)[:: c["stride"]].numpy()
+            g1[name + "/p_up_sum"] = np.array(p_up.double().sum().item())
+        # self-attention call (context=None) must not store
+        with torch.no_grad():
+            out_self = mod_self.forward(x)
+        assert len(ctrl.step_store["attn"]) == 1
+        g1[name + "/out_self_strided"] = out_self.reshape(-1)[::7].numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_hook.npz"), **g1)
+
+    # ---------------- G2: collect_maps on a 4-layer store -----------------------------
+    c = STACK_CASE
+    mods = [CrossAttention(Cl, c["ctx_dim"], c["heads"]) for (sl, Cl) in c["layers"]]
+    for i, m in enumerate(mods):
+        load_weights_into(m, c["seed"] + i)
+    # a 5th qualifying cross layer that must NOT be stored (gate len<4, ptp_utils.py:511)
+    extra = CrossAttention(c["layers"][0][1], c["ctx_dim"], c["heads"])
+    load_weights_into(extra, c["seed"] + 9)
+    net = Net(mods + [extra])
+    ctrl = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(net, ctrl, feature_upsample_res=c["R"])
+    assert ctrl.num_att_layers == 5
+    ctx = seeded((1, c["T"], c["ctx_dim"]), c["seed"] + 200)
+
+    def run_stack():
+        for i, (m, (sl, Cl)) in enumerate(zip(mods + [extra], c["layers"] + [c["layers"][0]])):
+            x = seeded((1, sl * sl, Cl), c["seed"] + 100 + i)
+            m.forward(x, context=ctx)
+        assert len(ctrl.step_store["attn"]) == 4
+
+    g2 = {}
+    idx = torch.tensor(c["indices"])
+    with torch.no_grad():
+        for tag, kw in {
+            "res-1": dict(upsample_res=-1),
+            "resR": dict(upsample_res=c["R"]),
+            "res24": dict(upsample_res=24),
+            "res-1_idx": dict(upsample_res=-1, indices=idx),
+            "res40_idx": dict(upsample_res=40, indices=idx),
+            "res-1_layers02": dict(upsample_res=-1, layers=[0, 2]),
+        }.items():
+            run_stack()
+            m = optimize.collect_maps(ctrl, **kw)
+            assert len(ctrl.step_store["attn"]) == 0        # collect_maps resets
+            g2[tag] = m.numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_collect_maps.npz"), **g2)
+
+    # ---------------- G3: selection on fixed maps -------------------------------------
+    s = SEL_CASE
+    from oracle.fixtures import selection_maps
+    maps, maps_t = selection_maps()
+    g3 = {}
+    g3["find_max_pixel"] = ref_eval.find_max_pixel(maps).numpy()
+    g3["find_k_max_pixels_1"] = ref_eval.find_k_max_pixels(maps, num=1).numpy()
+    g3["find_k_max_pixels_2"] = ref_eval.find_k_max_pixels(maps, num=2).numpy()
+    g3["mask_radius"] = ref_eval.mask_radius(maps[:3], ref_eval.find_max_pixel(maps[:3]), 0.05 * maps.shape[1]).numpy()
+    for ns in (1, 2):
+        top = ptp_utils.find_top_k_gaussian(maps, s["n_cand"], sigma=s["sigma"], num_subjects=ns)
+        g3[f"top_k_gaussian_ns{ns}"] = top.numpy()
+        # also the KL values themselves (restated from the reference lines, via its helpers)
+        loc = ref_eval.find_k_max_pixels(maps, num=ns) / maps.shape[1]
+        sm = torch.softmax(maps.view(maps.shape[0], -1) + 1e-5, dim=-1)
+        tgt = optimize_token.gaussian_circles(loc, size=maps.shape[1], sigma=s["sigma"], device="cpu")
+        tgt = tgt.reshape(maps.shape[0], -1) + 1e-5
+        tgt = tgt / tgt.sum(dim=-1, keepdim=True)
+        g3[f"kl_ns{ns}"] = torch.sum(tgt * (torch.log(tgt) - torch.log(sm)), dim=-1).numpy()
+        fps = ptp_utils.furthest_point_sampling(maps_t, s["top_k"], top)
+        g3[f"fps_ns{ns}"] = fps.numpy()
+    np.savez_compressed(os.path.join(OUT, "g3_selection.npz"), **g3)
+
+    # ---------------- G4: losses (+ gradients) and G7: gaussian / affine ---------------
+    g4 = {}
+    theta = inv.RandomAffineWithInverse().create_affine_matrix(11.0, 0.87, (0.13, -0.21))
+    theta2 = inv.RandomAffineWithInverse().create_affine_matrix(-14.0, 0.95, (-0.2, 0.05))
+    thetas = torch.cat([theta, theta2], dim=0)
+    g4["theta"] = thetas.numpy()
+    sel = torch.tensor(s["sel"])
+    for ns in (1, 2):
+        a = maps[sel].clone().requires_grad_(True)
+        l = optimize.sharpening_loss(a, sigma=s["sigma"], device="cpu", num_subjects=ns)
+        l.backward()
+        g4[f"sharp_ns{ns}"] = np.array(l.item(), dtype=np.float64)
+        g4[f"sharp_grad_ns{ns}"] = a.grad.numpy()
+    tr = inv.RandomAffineWithInverse()
+    tr.last_params = {"theta": thetas}
+    for index in (0, 1):
+        a = maps[sel].clone().requires_grad_(True)
+        b = maps_t[sel].clone().requires_grad_(True)
+        l = optimize.equivariance_loss(a, b[None].repeat(2, 1, 1, 1), tr, index)
+        l.backward()
+        g4[f"equiv_{index}"] = np.array(l.item(), dtype=np.float64)
+        g4[f"equiv_grad_a_{index}"] = a.grad.numpy()
+        g4[f"equiv_grad_b_{index}"] = b.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_losses.npz"), **g4)
+
+    g7 = {}
+    pos = torch.tensor([[[0.3, 0.7], [0.5, 0.5], [0.02, 0.98]], [[0.9, 0.1], [0.25, 0.75], [0.6, 0.4]]])
+    g7["gaussian_circle"] = optimize_token.gaussian_circle(pos[0], size=24, sigma=2.0, device="cpu").numpy()
+    g7["gaussian_circles"] = optimize_token.gaussian_circles(pos, size=24, sigma=3.0, device="cpu").numpy()
+    img = seeded((2, 3, 20, 28), 77).abs()
+    tr = inv.RandomAffineWithInverse(degrees=15, scale=(0.8, 1.0), translate=(0.25, 0.25))
+    g7["warp"] = tr(img, theta=thetas).numpy()
+    g7["unwarp"] = tr.inverse(tr(img, theta=thetas)).numpy()
+    # the random draw order: seed torch's global RNG, record theta
+    torch.manual_seed(1234)
+    _ = tr(img)
+    g7["theta_seed1234"] = tr.last_params["theta"].numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_gauss_affine.npz"), **g7)
+
+    # ---------------- G5/G6: hook-subgraph gradient and one Adam step ------------------
+    e = E2E_CASE
+    mods = [CrossAttention(Cl, e["ctx_dim"], e["heads"]) for (sl, Cl) in e["layers"]]
+    for i, m in enumerate(mods):
+        load_weights_into(m, e["seed"] + i)
+        for p in m.parameters():
+            p.requires_grad = False
+    net = Net(mods)
+    ctrl = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(net, ctrl, feature_upsample_res=e["R"])
+    context = seeded((1, e["T"], e["ctx_dim"]), e["seed"] + 200).requires_grad_(True)
+    opt = torch.optim.Adam([context], lr=5e-3)
+
+    def forward_maps(view):
+        for i, (m, (sl, Cl)) in enumerate(zip(mods, e["layers"])):
+            x = seeded((1, sl * sl, Cl), e["seed"] + 100 + 10 * view + i)
+            m.forward(x, context=context)
+        return optimize.collect_maps(ctrl, upsample_res=-1, layers=[0, 1, 2, 3])
+
+    am = forward_maps(0)
+    am_t = forward_maps(1)
+    top = ptp_utils.find_top_k_gaussian(am, e["n_cand"], sigma=e["sigma"], num_subjects=1)
+    sel = ptp_utils.furthest_point_sampling(am_t, e["top_k"], top)
+    tr = inv.RandomAffineWithInverse()
+    tr.last_params = {"theta": theta}
+    sharp = optimize.sharpening_loss(am[sel], device="cpu", sigma=e["sigma"], num_subjects=1)
+    equiv = optimize.equivariance_loss(am[sel], am_t[sel][None].repeat(1, 1, 1, 1), tr, 0)
+    loss = equiv * 1000.0 + sharp * 100.0
+    loss.backward()
+    g5 = {
+        "map": am.detach().numpy(), "map_t": am_t.detach().numpy(), "cand": top.numpy(),
+        "sel": sel.numpy(), "sharp": np.array(sharp.item()), "equiv": np.array(equiv.item()),
+        "loss": np.array(loss.item()), "context_grad": context.grad.numpy().copy(),
+    }
+    opt.step()
+    g5["context_after_adam"] = context.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g5_subgraph.npz"), **g5)
+
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden written to", OUT, "total bytes", tot)
+
+
+if __name__ == "__main__":
+    main()

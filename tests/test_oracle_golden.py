@@ -1,0 +1,168 @@
+"""Pin the CPU oracle (oracle/ref_path.py) to golden vectors captured from the REFERENCE's own
+functions (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_path as R
+from oracle.fixtures import (HOOK_CASES, STACK_CASE, SEL_CASE, E2E_CASE, attention_weights, seeded,
+                             selection_maps)
+
+TOL = dict(rtol=2e-5, atol=2e-7)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("name", list(HOOK_CASES))
+def test_g1_hook(golden, name):
+    g = golden("g1_hook.npz")
+    c = HOOK_CASES[name]
+    w = attention_weights(c["C"], c["ctx_dim"], c["seed"])
+    x = seeded((c["B"], c["s"] ** 2, c["C"]), c["seed"] + 100)
+    ctx = seeded((c["B"], c["T"], c["ctx_dim"]), c["seed"] + 200)
+    store = R.OracleStore()
+    out = R.hooked_attention(x, ctx, *w, c["heads"], store, c["R"])
+    assert len(store.step_store["attn"]) == 1
+    p_up = store.step_store["attn"][0]
+    assert p_up.shape == (c["B"] * c["heads"], c["R"] ** 2, c["T"])
+    if c["full"]:
+        torch.testing.assert_close(p_up, t(g[name + "/p_up"]), **TOL)
+        torch.testing.assert_close(out, t(g[name + "/out"]), rtol=1e-4, atol=1e-5)
+    else:
+        torch.testing.assert_close(p_up.reshape(-1)[:: c["stride"]], t(g[name + "/p_up_strided"]), rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(out.reshape(-1)[:: c["stride"]], t(g[name + "/out_strided"]), rtol=1e-4, atol=1e-5)
+        assert abs(p_up.double().sum().item() - float(g[name + "/p_up_sum"])) < 1e-2
+    # self-attention (context=None) never stores  (ptp_utils.py:509)
+    ws = attention_weights(c["C"], c["C"], c["seed"] + 1000)
+    out_self = R.hooked_attention(x, None, *ws, c["heads"], store, c["R"])
+    assert len(store.step_store["attn"]) == 1
+    torch.testing.assert_close(out_self.reshape(-1)[::7], t(g[name + "/out_self_strided"]), rtol=1e-4, atol=1e-5)
+
+
+def _stack_store(case, ctx, view=0, max_layers=5):
+    store = R.OracleStore()
+    layers = case["layers"] + [case["layers"][0]]
+    seeds = [case["seed"] + i for i in range(4)] + [case["seed"] + 9]
+    for i, ((sl, Cl), sd) in enumerate(zip(layers[:max_layers], seeds)):
+        w = attention_weights(Cl, case["ctx_dim"], sd)
+        x = seeded((1, sl * sl, Cl), case["seed"] + 100 + 10 * view + i)
+        R.hooked_attention(x, ctx, *w, case["heads"], store, case["R"])
+    return store
+
+
+def test_g2_collect_maps(golden):
+    g = golden("g2_collect_maps.npz")
+    c = STACK_CASE
+    ctx = seeded((1, c["T"], c["ctx_dim"]), c["seed"] + 200)
+    idx = torch.tensor(c["indices"])
+    cases = {
+        "res-1": dict(upsample_res=-1),
+        "resR": dict(upsample_res=c["R"]),
+        "res24": dict(upsample_res=24),
+        "res-1_idx": dict(upsample_res=-1, indices=idx),
+        "res40_idx": dict(upsample_res=40, indices=idx),
+        "res-1_layers02": dict(upsample_res=-1, layers=[0, 2]),
+    }
+    for tag, kw in cases.items():
+        store = _stack_store(c, ctx)
+        assert len(store.step_store["attn"]) == 4          # the 5th layer is gated out
+        m = R.collect_maps(store, **kw)
+        assert len(store.step_store["attn"]) == 0          # reset (optimize.py:77)
+        torch.testing.assert_close(m, t(g[tag]), **TOL)
+    # invariant: probabilities over tokens sum to 1 at every pixel
+    m = R.collect_maps(_stack_store(c, ctx), upsample_res=-1)
+    torch.testing.assert_close(m.sum(0), torch.ones(c["R"], c["R"]), rtol=1e-5, atol=1e-5)
+
+
+def test_g3_selection(golden):
+    g = golden("g3_selection.npz")
+    s = SEL_CASE
+    maps, maps_t = selection_maps()
+    assert torch.equal(R.find_max_pixel(maps), t(g["find_max_pixel"]))
+    assert R.find_max_pixel(maps)[5].tolist() == [3.5, 4.5]          # first index wins the tie
+    assert torch.equal(R.find_k_max_pixels(maps, 1), t(g["find_k_max_pixels_1"]))
+    assert torch.equal(R.find_k_max_pixels(maps, 2), t(g["find_k_max_pixels_2"]))
+    assert torch.equal(R.mask_radius(maps[:3], R.find_max_pixel(maps[:3]), 0.05 * s["R"]), t(g["mask_radius"]))
+    for ns in (1, 2):
+        kl = R.gaussian_kl(maps, s["sigma"], num_subjects=ns)
+        torch.testing.assert_close(kl, t(g[f"kl_ns{ns}"]), rtol=1e-5, atol=1e-6)
+        top = R.find_top_k_gaussian(maps, s["n_cand"], sigma=s["sigma"], num_subjects=ns)
+        assert torch.equal(top, t(g[f"top_k_gaussian_ns{ns}"]))
+        fps = R.furthest_point_sampling(maps_t, s["top_k"], top)
+        assert torch.equal(fps, t(g[f"fps_ns{ns}"]))
+
+
+def test_g4_losses(golden):
+    g = golden("g4_losses.npz")
+    s = SEL_CASE
+    maps, maps_t = selection_maps()
+    sel = torch.tensor(s["sel"])
+    thetas = t(g["theta"])
+    torch.testing.assert_close(torch.cat([R.affine_matrix(11.0, 0.87, (0.13, -0.21)),
+                                          R.affine_matrix(-14.0, 0.95, (-0.2, 0.05))]), thetas, rtol=0, atol=0)
+    for ns in (1, 2):
+        a = maps[sel].clone().requires_grad_(True)
+        l = R.sharpening_loss(a, sigma=s["sigma"], num_subjects=ns)
+        l.backward()
+        assert abs(l.item() - float(g[f"sharp_ns{ns}"])) <= 1e-6 * abs(float(g[f"sharp_ns{ns}"]))
+        torch.testing.assert_close(a.grad, t(g[f"sharp_grad_ns{ns}"]), **TOL)
+    for index in (0, 1):
+        a = maps[sel].clone().requires_grad_(True)
+        b = maps_t[sel].clone().requires_grad_(True)
+        l = R.equivariance_loss(a, b, thetas, index)
+        l.backward()
+        assert abs(l.item() - float(g[f"equiv_{index}"])) <= 1e-6 * abs(float(g[f"equiv_{index}"]))
+        torch.testing.assert_close(a.grad, t(g[f"equiv_grad_a_{index}"]), **TOL)
+        torch.testing.assert_close(b.grad, t(g[f"equiv_grad_b_{index}"]), **TOL)
+
+
+def test_g7_gauss_affine(golden):
+    g = golden("g7_gauss_affine.npz")
+    pos = torch.tensor([[[0.3, 0.7], [0.5, 0.5], [0.02, 0.98]], [[0.9, 0.1], [0.25, 0.75], [0.6, 0.4]]])
+    torch.testing.assert_close(R.gaussian_circle(pos[0], 24, 2.0), t(g["gaussian_circle"]), **TOL)
+    torch.testing.assert_close(R.gaussian_circles(pos, 24, 3.0), t(g["gaussian_circles"]), **TOL)
+    thetas = torch.cat([R.affine_matrix(11.0, 0.87, (0.13, -0.21)), R.affine_matrix(-14.0, 0.95, (-0.2, 0.05))])
+    img = seeded((2, 3, 20, 28), 77).abs()
+    w = R.affine_warp(img, thetas)
+    torch.testing.assert_close(w, t(g["warp"]), **TOL)
+    torch.testing.assert_close(R.affine_unwarp(w, thetas), t(g["unwarp"]), **TOL)
+    # random draw order (invertable_transform.py:42-51): 4 uniforms per image from the global RNG
+    torch.manual_seed(1234)
+    th = []
+    for _ in range(2):
+        a, sc, tr = R.draw_affine_params(lambda: torch.rand(1).item(), 15, (0.8, 1.0), (0.25, 0.25))
+        th.append(R.affine_matrix(a, sc, tr))
+    torch.testing.assert_close(torch.cat(th), t(g["theta_seed1234"]), rtol=0, atol=0)
+
+
+def test_g5_subgraph_gradient_and_adam(golden):
+    g = golden("g5_subgraph.npz")
+    e = E2E_CASE
+    context = seeded((1, e["T"], e["ctx_dim"]), e["seed"] + 200).requires_grad_(True)
+    opt = torch.optim.Adam([context], lr=5e-3)
+    maps = []
+    for view in (0, 1):
+        store = _stack_store(e, context, view=view, max_layers=4)
+        maps.append(R.collect_maps(store, upsample_res=-1, layers=[0, 1, 2, 3]))
+    am, am_t = maps
+    torch.testing.assert_close(am, t(g["map"]), **TOL)
+    torch.testing.assert_close(am_t, t(g["map_t"]), **TOL)
+    theta = R.affine_matrix(11.0, 0.87, (0.13, -0.21))
+    loss, sharp, equiv, sel = R.image_loss(am, am_t, theta, 0, furthest_point_num_samples=e["n_cand"],
+                                           top_k=e["top_k"], sigma=e["sigma"])
+    assert torch.equal(sel, t(g["sel"]))
+    assert abs(sharp.item() - float(g["sharp"])) < 1e-5 * abs(float(g["sharp"]))
+    assert abs(equiv.item() - float(g["equiv"])) < 1e-5 * abs(float(g["equiv"]))
+    loss.backward()
+    torch.testing.assert_close(context.grad, t(g["context_grad"]), rtol=1e-4, atol=1e-7)
+    opt.step()
+    torch.testing.assert_close(context.detach(), t(g["context_after_adam"]), rtol=1e-6, atol=1e-6)
+
+
+def test_scheduler_restatement():
+    ts = R.ddim_timesteps()
+    assert ts[-1].item() == 0 and ts[0].item() == 980 and len(ts) == 50
+    acp = R.ddim_alphas_cumprod()
+    assert abs(acp[0].item() - (1 - 0.00085)) < 1e-7
