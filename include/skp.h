@@ -1,0 +1,116 @@
+/* skp.h -- C ABI of libskp_hip.so: the MI355X (gfx950) implementation of the StableKeypoints
+ * token-optimisation hot path.  Plain pointers + sizes only; no torch types.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked [host];
+ *     kernels never allocate, never synchronise, and launch on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream);
+ *   - tensors are dense, row-major, fp32 ("f32") unless stated; indices are int64 ("i64")
+ *     or int32 ("i32") as named;
+ *   - return value: 0 on success; a positive value is the hipError_t of the failed launch;
+ *     a negative value is an argument error (SKP_E_*).  Nothing is written on error.
+ *
+ * Reference interfaces replaced (paths relative to the reference's unsupervised_keypoints/):
+ *   skp_qk_logits_f32 / skp_gemm_nt_f32     ptp_utils.py:483-493,531-534 (q.k^T contractions)
+ *   skp_attn_map_fwd_f32 / _bwd_f32         ptp_utils.py:513-538 + optimize.py:27-79
+ *                                           (bicubic up-res softmax map, per-head store, layer/head mean)
+ *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
+ *   skp_select_tokens                       ptp_utils.py:110-112,115-159
+ *   skp_losses_fwd_f32                      optimize.py:157-206, optimize_token.py:203-241,
+ *                                           invertable_transform.py:72-92
+ *   skp_rows_axpy_f32                       autograd scatter of the loss gradients into [T,R,R]
+ */
+#ifndef SKP_H
+#define SKP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKP_MAX_LAYERS 8
+#define SKP_MAX_SUBJECTS 4
+
+#define SKP_E_BADARG (-1)   /* null pointer / non-positive size */
+#define SKP_E_RANGE  (-2)   /* size outside what the kernels are built for (see each function) */
+#define SKP_E_LDS    (-3)   /* tile does not fit the 160 KiB LDS of a gfx950 CU */
+
+/* ABI version; bumped on any signature change. */
+int skp_abi_version(void);
+
+/* Batched NT GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain):
+ *   C[z0,z1][m,n] = alpha * sum_k A[z0,z1][m,k] * B[z0,z1][n,k]          z0<Z0, z1<Z1
+ * with arbitrary element strides (sXm,sXk / sXn,sXk) and two batch strides per operand
+ * (a batch stride of 0 broadcasts).  C is written densely with strides (sc0,sc1,scm,1).
+ * Used for S_low = scale*K.Q^T and for its two backward products. */
+int skp_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, int Z0, int Z1,
+                    int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
+                    int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
+                    int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream);
+
+/* Low-resolution cross-attention logits of one hooked layer, log2 domain:
+ *   S[b,h,t,p] = (scale*log2(e)) * sum_c k[bk,t,h*d+c] * q[b,p,h*d+c]
+ * q: [B, s*s, H*d] (= to_q(x), ptp_utils.py:483), k: [Bk, T, H*d] with Bk in {1,B}
+ * (= to_k(context), :487; Bk==1 is the reference's context.repeat(B,1,1), ptp_utils.py:229),
+ * S: [B, H, T, s*s]. */
+int skp_qk_logits_f32(const float* q, const float* k, float* S, int B, int Bk, int H, int T, int s2,
+                      int d, float scale, void* stream);
+
+/* Fused up-res attention map (forward).  For every layer l<L (side s[l], logits S[l] from
+ * skp_qk_logits_f32), head h<H and output pixel p of the R x R grid:
+ *   P[l,h,t,p] = softmax_t( bicubic_{s[l]->R}(S[l][b,h,t,:,:])[p] )     (align_corners=False, A=-0.75)
+ *   M[b,t,p]   = 1/(L*H) * sum_{l,h} P[l,h,t,p]
+ * which equals collect_maps(upsample_res=-1) over the reference's stored tensors because
+ * to_q is bias-free and bicubic resize is linear.
+ * M:   [B, T, R, R]            (written)
+ * lse: [B, L*H, R*R]           (written; log2-sum-exp per (layer, head, pixel), needed by _bwd)
+ * Limits: 1 <= T <= 128, L <= SKP_MAX_LAYERS, s[l] <= 64.  */
+int skp_attn_map_fwd_f32(const float* const* S /*[host] L device ptrs*/, const int* s /*[host] L*/,
+                         int L, int B, int H, int T, int R, float* M, float* lse, void* stream);
+
+/* Backward of skp_attn_map_fwd_f32: dS[l] (natural-log domain, i.e. d loss / d (scale*q.k),
+ * shape of S[l]) += adjoint.  dS[l] must be ZERO-FILLED by the caller (accumulated with
+ * fp32 atomics across tiles).  dM: [B,T,R,R]. */
+int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/,
+                         const int* s /*[host]*/, int L, int B, int H, int T, int R,
+                         const float* dM, const float* lse, void* stream);
+
+/* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
+ *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects
+ *                         (first index wins ties; radius 0.05*R masking between maxima)
+ *   kl[t] = KL( normalised gaussian(sigma) at those maxima  ||  softmax_{R*R}(M[t]+eps) )
+ * kl may be NULL (argmax only). */
+int skp_token_stats_f32(const float* M, int T, int R, int num_subjects, float sigma, float eps,
+                        int32_t* argmax, float* kl, void* stream);
+
+/* Token selection (ptp_utils.py:110-112 + 115-159), entirely on device:
+ *   cand = first n_cand tokens of argsort(kl, ascending)
+ *   sel  = furthest_point_sampling over cand using the arg-max locations of the
+ *          TRANSFORMED map (argmax_t, i32 flat indices, grid side R)
+ * cand: i64[n_cand], sel: i64[top_k].  Limits: T <= 1024, n_cand <= 64, 2 <= top_k <= n_cand. */
+int skp_select_tokens(const float* kl, const int32_t* argmax_t, int T, int R, int n_cand, int top_k,
+                      int64_t* cand, int64_t* sel, void* stream);
+
+/* Sharpening + equivariance losses and their unit gradients for the K selected tokens
+ * (optimize.py:157-206):
+ *   sharp = mean_{k,p} (M[sel[k],p] - G[k,p])^2,  G = mean_j gaussian at argmax[j*T+sel[k]]
+ *   equiv = mean_{k,p} (M[sel[k],p] - unwarp(Mt[sel[k]], theta_inv)[p])^2
+ * theta_inv [host] 6 floats = the 2x3 INVERSE affine (invertable_transform.py:77-84); the
+ * warp is affine_grid + bilinear grid_sample, zeros padding, align_corners=False.
+ * partial: [2,K,nchunk] sums of squares, nchunk = ceil(R*R/1024) (caller sums, divides by K*R*R);
+ * g_sharp, g_eq_a: [K,R,R] written = d sharp / d M[sel], d equiv / d M[sel];
+ * g_eq_b: [K,R,R] must be ZERO-FILLED, accumulates d equiv / d Mt[sel] (fp32 atomics). */
+int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
+                       const int32_t* argmax, int num_subjects, float sigma,
+                       const float* theta_inv /*[host] 6*/, float* partial, float* g_sharp,
+                       float* g_eq_a, float* g_eq_b, void* stream);
+
+/* dst[sel[k], :] += a * x[k, :] + b * y[k, :]   (y may be NULL); rows of length n; sel i64[K] distinct. */
+int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t n, const float* x, const float* a,
+                      const float* y, const float* b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKP_H */

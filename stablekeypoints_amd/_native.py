@@ -1,0 +1,92 @@
+"""ctypes binding of libskp_hip.so (the C-ABI declared in include/skp.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing the
+native ops raises.  The product path never routes through `oracle/` or through eager PyTorch
+re-implementations of these kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
+ABI_VERSION = 1
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes   (restype is always int)
+SIGNATURES = {
+    "skp_abi_version": [],
+    "skp_gemm_nt_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i,
+                        _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp],
+    "skp_qk_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_attn_map_fwd_f32": [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "skp_attn_map_bwd_f32": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "skp_token_stats_f32": [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp],
+    "skp_select_tokens": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "skp_losses_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, C.POINTER(_f), _vp, _vp, _vp, _vp, _vp],
+    "skp_rows_axpy_f32": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
+    "skp_cross_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_cross_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_self_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "skp_self_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+}
+
+_ERR = {-1: "SKP_E_BADARG (null pointer / non-positive size)",
+        -2: "SKP_E_RANGE (size outside the built kernel range)",
+        -3: "SKP_E_LDS (tile exceeds 160 KiB LDS)"}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the CDLL; raises NativeLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C stablekeypoints_amd/csrc`). There is no CPU/eager fallback for the hot path.")
+    l = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        if not hasattr(l, name):
+            if name.startswith(("skp_cross_attn", "skp_self_attn")):
+                continue                       # optional until built (declared in skp.h only when present)
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}")
+        fn = getattr(l, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    v = l.skp_abi_version()
+    if v != ABI_VERSION:
+        raise NativeLibraryError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {_ERR.get(rc, rc)}")
+    raise RuntimeError(f"{what}: HIP launch failed with hipError_t={rc}")
+
+
+def ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) for p in ptrs])
+    return C.cast(arr, C.POINTER(C.c_void_p)), arr
+
+
+def int_array(vals):
+    arr = (C.c_int * len(vals))(*[int(v) for v in vals])
+    return C.cast(arr, C.POINTER(C.c_int)), arr
+
+
+def float_array(vals):
+    arr = (C.c_float * len(vals))(*[float(v) for v in vals])
+    return C.cast(arr, C.POINTER(C.c_float)), arr

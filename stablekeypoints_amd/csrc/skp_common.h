@@ -1,0 +1,60 @@
+// Shared device helpers for libskp_hip.so (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/skp.h"
+
+#define SKP_WAVE 64
+#define SKP_LOG2E 1.4426950408889634f
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int skp_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// PyTorch upsample_bicubic2d taps (align_corners=False, A=-0.75): source coordinate is NOT
+// clamped for cubic mode; tap indices are clamped to [0, n-1] on access.
+__device__ __forceinline__ void skp_cubic_taps(int dst, float ratio, int n, int idx[4], float w[4]) {
+    const float A = -0.75f;
+    const float src = ratio * ((float)dst + 0.5f) - 0.5f;
+    const float fl = floorf(src);
+    const float t = src - fl;
+    const int i0 = (int)fl;
+    float x = t + 1.0f;
+    w[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    w[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    w[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    w[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int v = i0 - 1 + i;
+        idx[i] = v < 0 ? 0 : (v > n - 1 ? n - 1 : v);
+    }
+}
+
+// 64-lane butterfly reductions (all lanes end with the result).
+__device__ __forceinline__ float skp_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float skp_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Deterministic block sum for 256-thread blocks; `red` = 4 floats of LDS. All threads get the result.
+__device__ __forceinline__ float skp_block_sum_256(float v, float* red) {
+    v = skp_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}

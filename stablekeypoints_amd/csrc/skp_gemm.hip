@@ -1,0 +1,80 @@
+// Batched NT GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): exact fp32 fma chain,
+// 157 TF/s peak on MI355X.  Replaces the q.k^T contractions of ptp_utils.py:493,534 and their
+// backward products.  One wave owns one 32x32 output tile; operands are read straight from
+// global/L2 (the matrices of this path are <= a few MB and L2 resident), K is walked 2 at a
+// time: lane l supplies A[m0 + (l&31)][k0 + (l>>5)] and B[n0 + (l&31)][k0 + (l>>5)].
+#include "skp_common.h"
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K, Z1;
+    int64_t sa0, sa1, sam, sak;
+    int64_t sb0, sb1, sbn, sbk;
+    int64_t sc0, sc1, scm;
+    float alpha;
+};
+
+__global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, hi = lane >> 5;
+    const int n0 = (blockIdx.x * 2 + (wave & 1)) * 32;
+    const int m0 = (blockIdx.y * 2 + (wave >> 1)) * 32;
+    if (m0 >= g.M || n0 >= g.N) return;                       // wave-uniform
+    const int z0 = blockIdx.z / g.Z1, z1 = blockIdx.z - z0 * g.Z1;
+    const bool mv = (m0 + i) < g.M, nv = (n0 + i) < g.N;
+    const float* Ap = g.A + z0 * g.sa0 + z1 * g.sa1 + (int64_t)(mv ? m0 + i : 0) * g.sam + hi * g.sak;
+    const float* Bp = g.B + z0 * g.sb0 + z1 * g.sb1 + (int64_t)(nv ? n0 + i : 0) * g.sbn + hi * g.sbk;
+    f32x16 acc = {0};
+    const int K = g.K;
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {                               // 4 MFMAs per trip, loads issued first
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = Ap[(int64_t)(k + 2 * u) * g.sak];
+            b[u] = Bp[(int64_t)(k + 2 * u) * g.sbk];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mv ? a[u] : 0.f, nv ? b[u] : 0.f, acc, 0, 0, 0);
+    }
+    for (; k < K; k += 2) {
+        const bool kv = (k + hi) < K;
+        const float a = (kv && mv) ? Ap[(int64_t)k * g.sak] : 0.f;
+        const float b = (kv && nv) ? Bp[(int64_t)k * g.sbk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
+    float* Cp = g.C + z0 * g.sc0 + z1 * g.sc1;
+    if (nv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m < g.M) Cp[(int64_t)m * g.scm + n0 + i] = g.alpha * acc[r];
+        }
+    }
+}
+
+extern "C" int skp_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, int Z0, int Z1,
+                               int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
+                               int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
+                               int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || Z0 <= 0 || Z1 <= 0) return SKP_E_BADARG;
+    if ((int64_t)Z0 * Z1 > 65535) return SKP_E_RANGE;
+    GemmArgs g{A, B, C, M, N, K, Z1, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
+    dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1);
+    hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return skp_launch_status();
+}
+
+extern "C" int skp_qk_logits_f32(const float* q, const float* k, float* S, int B, int Bk, int H, int T, int s2,
+                                 int d, float scale, void* stream) {
+    if (!q || !k || !S || B <= 0 || H <= 0 || T <= 0 || s2 <= 0 || d <= 0) return SKP_E_BADARG;
+    if (Bk != 1 && Bk != B) return SKP_E_BADARG;
+    const int64_t C = (int64_t)H * d;
+    // S[b,h][t,p] = alpha * sum_c k[b,t,h*d+c] * q[b,p,h*d+c]
+    return skp_gemm_nt_f32(k, q, S, T, s2, d, B, H,
+                           Bk == 1 ? 0 : (int64_t)T * C, d, C, 1,
+                           (int64_t)s2 * C, d, C, 1,
+                           (int64_t)H * T * s2, (int64_t)T * s2, s2, scale * SKP_LOG2E, stream);
+}

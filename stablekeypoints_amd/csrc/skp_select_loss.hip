@@ -1,0 +1,300 @@
+// Token statistics, on-device token selection, and the sharpening / equivariance losses.
+// HBM-bound reductions over the reduced map M [T,R,R] (5 MB at T=77, R=128) + a latency-bound
+// single-workgroup selection that replaces ~500 tiny launches and .item() syncs of the reference
+// (ptp_utils.py:115-159).
+#include "skp_common.h"
+
+// (value desc, index asc) ordering == torch.argmax "first maximal index".
+__device__ __forceinline__ bool skp_better(float v, int i, float bv, int bi) {
+    return (v > bv) || (v == bv && i < bi);
+}
+
+struct StatsArgs { int T, R, S; float sigma, eps; };
+
+// One workgroup per token.  eval.py:39-111 (find_max_pixel / find_k_max_pixels / mask_radius),
+// ptp_utils.py:95-108 (KL against the normalised gaussian), optimize_token.py:203-241.
+__global__ __launch_bounds__(256) void skp_token_stats_kernel(const float* __restrict__ M, StatsArgs a,
+                                                              int32_t* __restrict__ argmax_out,
+                                                              float* __restrict__ kl_out) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ float red[4];
+    __shared__ float s_cy[SKP_MAX_SUBJECTS], s_cx[SKP_MAX_SUBJECTS];   // centres incl. the +0.5 offset
+    const int t = blockIdx.x, tid = threadIdx.x, R = a.R, RR = R * R;
+    const float* m = M + (size_t)t * RR;
+    const float rad = 0.05f * (float)R;                         // eval.py:79
+    const float rad2 = rad * rad;
+    float maxval0 = 0.f;
+    for (int j = 0; j < a.S; ++j) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int p = tid; p < RR; p += 256) {
+            const int row = p / R, col = p - row * R;
+            float v = m[p];
+            for (int q = 0; q < j; ++q) {                       // cumulative masks (eval.py:81,100-109)
+                const float dx = (float)col - s_cx[q], dy = (float)row - s_cy[q];
+                const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                v = v * ((d2 > rad2) ? 1.0f : 0.0f);
+            }
+            if (skp_better(v, p, bv, bi)) { bv = v; bi = p; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (skp_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+        __syncthreads();
+        bv = red_v[0]; bi = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) if (skp_better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
+        if (tid == 0) {
+            argmax_out[j * a.T + t] = bi;
+            s_cy[j] = (float)(bi / R) + 0.5f;
+            s_cx[j] = (float)(bi % R) + 0.5f;
+        }
+        if (j == 0) maxval0 = bv;
+        __syncthreads();
+    }
+    if (!kl_out) return;
+    // gaussian centres in pixels: (loc / R) * R, fp32 like the reference (ptp_utils.py:97, optimize_token.py:210)
+    float pcy[SKP_MAX_SUBJECTS], pcx[SKP_MAX_SUBJECTS];
+    for (int j = 0; j < a.S; ++j) {
+        pcy[j] = __fmul_rn(__fdiv_rn(s_cy[j], (float)R), (float)R);
+        pcx[j] = __fmul_rn(__fdiv_rn(s_cx[j], (float)R), (float)R);
+    }
+    const float two_sig2 = 2.0f * a.sigma * a.sigma;
+    const float inv_S = 1.0f / (float)a.S;
+    const float mx = maxval0 + a.eps;
+    // pass B: softmax denominator and gaussian normaliser
+    float se = 0.f, zg = 0.f;
+    for (int p = tid; p < RR; p += 256) {
+        const int row = p / R, col = p - row * R;
+        se += expf(m[p] + a.eps - mx);
+        float g = 0.f;
+        for (int j = 0; j < a.S; ++j) {
+            const float dx = (float)col + 0.5f - pcx[j], dy = (float)row + 0.5f - pcy[j];
+            g += expf(-(dx * dx + dy * dy) / two_sig2);
+        }
+        zg += g * inv_S + a.eps;
+    }
+    se = skp_block_sum_256(se, red);
+    zg = skp_block_sum_256(zg, red);
+    // pass C: KL(target || softmax)
+    float kl = 0.f;
+    for (int p = tid; p < RR; p += 256) {
+        const int row = p / R, col = p - row * R;
+        const float sm = expf(m[p] + a.eps - mx) / se;
+        float g = 0.f;
+        for (int j = 0; j < a.S; ++j) {
+            const float dx = (float)col + 0.5f - pcx[j], dy = (float)row + 0.5f - pcy[j];
+            g += expf(-(dx * dx + dy * dy) / two_sig2);
+        }
+        const float tn = (g * inv_S + a.eps) / zg;
+        kl += tn * (logf(tn) - logf(sm));
+    }
+    kl = skp_block_sum_256(kl, red);
+    if (tid == 0) kl_out[t] = kl;
+}
+
+extern "C" int skp_token_stats_f32(const float* M, int T, int R, int num_subjects, float sigma, float eps,
+                                   int32_t* argmax, float* kl, void* stream) {
+    if (!M || !argmax || T <= 0 || R <= 0) return SKP_E_BADARG;
+    if (num_subjects < 1 || num_subjects > SKP_MAX_SUBJECTS || R > 4096) return SKP_E_RANGE;
+    StatsArgs a{T, R, num_subjects, sigma, eps};
+    hipLaunchKernelGGL(skp_token_stats_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, M, a, argmax, kl);
+    return skp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Selection: ascending-KL candidates + furthest point sampling.  ptp_utils.py:110-112,115-159.
+// ---------------------------------------------------------------------------------------------
+#define SKP_SEL_MAXT 1024
+#define SKP_SEL_MAXC 64
+
+__device__ __forceinline__ float skp_dist(float ay, float ax, float by, float bx) {
+    const float dy = __fsub_rn(ay, by), dx = __fsub_rn(ax, bx);     // no fma contraction: keep ties exact
+    return __fsqrt_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)));
+}
+
+__global__ __launch_bounds__(256) void skp_select_kernel(const float* __restrict__ kl,
+                                                         const int32_t* __restrict__ argmax_t, int T, int R,
+                                                         int n_cand, int top_k, int64_t* __restrict__ cand_out,
+                                                         int64_t* __restrict__ sel_out) {
+    __shared__ float s_kl[SKP_SEL_MAXT];
+    __shared__ int s_cand[SKP_SEL_MAXC];
+    __shared__ float s_ly[SKP_SEL_MAXC], s_lx[SKP_SEL_MAXC];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < T; i += 256) s_kl[i] = kl[i];
+    __syncthreads();
+    for (int i = tid; i < T; i += 256) {                        // rank by (kl asc, index asc)
+        const float v = s_kl[i];
+        int rank = 0;
+        for (int j = 0; j < T; ++j) {
+            const float u = s_kl[j];
+            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+        }
+        if (rank < n_cand) s_cand[rank] = i;
+    }
+    __syncthreads();
+    if (tid < n_cand) {
+        const int tok = s_cand[tid];
+        const int flat = argmax_t[tok];
+        // find_max_pixel(...)/image_h : (row+0.5)/R, (col+0.5)/R     ptp_utils.py:127
+        s_ly[tid] = __fdiv_rn((float)(flat / R) + 0.5f, (float)R);
+        s_lx[tid] = __fdiv_rn((float)(flat % R) + 0.5f, (float)R);
+        cand_out[tid] = tok;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    int chosen[SKP_SEL_MAXC];                                   // candidate slots
+    int nch = 0;
+    float best = -1.0f; int ba = 0, bb = 1;
+    for (int i = 0; i < n_cand; ++i)                            // ptp_utils.py:132-137
+        for (int j = i + 1; j < n_cand; ++j) {
+            const float d = skp_dist(s_ly[i], s_lx[i], s_ly[j], s_lx[j]);
+            if (d > best) { best = d; ba = i; bb = j; }
+        }
+    chosen[nch++] = ba; chosen[nch++] = bb;
+    for (int it = 0; it < top_k - 2; ++it) {                    // ptp_utils.py:142-157
+        float far = -1.0f; int fi = -1;
+        for (int i = 0; i < n_cand; ++i) {
+            bool taken = false;
+            for (int q = 0; q < nch; ++q) taken |= (s_cand[chosen[q]] == s_cand[i]);
+            if (taken) continue;
+            float dmin = INFINITY;
+            for (int q = 0; q < nch; ++q)
+                dmin = fminf(dmin, skp_dist(s_ly[i], s_lx[i], s_ly[chosen[q]], s_lx[chosen[q]]));
+            if (dmin > far) { far = dmin; fi = i; }
+        }
+        if (fi >= 0) chosen[nch++] = fi;
+    }
+    for (int q = 0; q < top_k; ++q) sel_out[q] = (q < nch) ? (int64_t)s_cand[chosen[q]] : (int64_t)s_cand[chosen[nch - 1]];
+}
+
+extern "C" int skp_select_tokens(const float* kl, const int32_t* argmax_t, int T, int R, int n_cand, int top_k,
+                                 int64_t* cand, int64_t* sel, void* stream) {
+    if (!kl || !argmax_t || !cand || !sel || T <= 0 || R <= 0) return SKP_E_BADARG;
+    if (T > SKP_SEL_MAXT || n_cand > SKP_SEL_MAXC || n_cand > T || top_k < 2 || top_k > n_cand) return SKP_E_RANGE;
+    hipLaunchKernelGGL(skp_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kl, argmax_t, T, R, n_cand,
+                       top_k, cand, sel);
+    return skp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Losses (optimize.py:157-206) with their unit gradients, fused: one pass over the K selected rows.
+// grid = (ceil(R*R/1024), K); each thread handles 4 strided pixels.
+// ---------------------------------------------------------------------------------------------
+struct LossArgs {
+    int K, T, R, S, nchunk;
+    float sigma;
+    float th[6];                                                // inverse affine, row-major 2x3
+};
+
+__global__ __launch_bounds__(256) void skp_losses_kernel(const float* __restrict__ M, const float* __restrict__ Mt,
+                                                         const int64_t* __restrict__ sel,
+                                                         const int32_t* __restrict__ argmax, LossArgs a,
+                                                         float* __restrict__ partial, float* __restrict__ g_sharp,
+                                                         float* __restrict__ g_eq_a, float* __restrict__ g_eq_b) {
+    __shared__ float red[4];
+    const int k = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int R = a.R, RR = R * R;
+    const int tok = (int)sel[k];
+    const float* m = M + (size_t)tok * RR;
+    const float* mt = Mt + (size_t)tok * RR;
+    float pcy[SKP_MAX_SUBJECTS], pcx[SKP_MAX_SUBJECTS];
+    for (int j = 0; j < a.S; ++j) {                             // optimize.py:168 + optimize_token.py:210
+        const int flat = argmax[j * a.T + tok];
+        pcy[j] = __fmul_rn(__fdiv_rn((float)(flat / R) + 0.5f, (float)R), (float)R);
+        pcx[j] = __fmul_rn(__fdiv_rn((float)(flat % R) + 0.5f, (float)R), (float)R);
+    }
+    const float two_sig2 = 2.0f * a.sigma * a.sigma;
+    const float inv_S = 1.0f / (float)a.S;
+    const float gscale = 2.0f / ((float)a.K * (float)RR);       // d mean((a-b)^2) / d a = 2 (a-b) / n
+    float ss = 0.f, se = 0.f;
+    for (int u = 0; u < 4; ++u) {
+        const int p = chunk * 1024 + u * 256 + tid;
+        if (p >= RR) break;
+        const int row = p / R, col = p - row * R;
+        const float v = m[p];
+        // --- sharpening: gaussian target at the token's own arg-maxima
+        float g = 0.f;
+        for (int j = 0; j < a.S; ++j) {
+            const float dx = (float)col + 0.5f - pcx[j], dy = (float)row + 0.5f - pcy[j];
+            g += expf(-(dx * dx + dy * dy) / two_sig2);
+        }
+        const float ds = v - g * inv_S;
+        ss += ds * ds;
+        g_sharp[(size_t)k * RR + p] = gscale * ds;
+        // --- equivariance: bilinear sample of the transformed map through the inverse affine
+        const float xs = (2.0f * (float)col + 1.0f) / (float)R - 1.0f;
+        const float ys = (2.0f * (float)row + 1.0f) / (float)R - 1.0f;
+        const float gx = a.th[0] * xs + a.th[1] * ys + a.th[2];
+        const float gy = a.th[3] * xs + a.th[4] * ys + a.th[5];
+        const float fx = ((gx + 1.0f) * (float)R - 1.0f) * 0.5f;
+        const float fy = ((gy + 1.0f) * (float)R - 1.0f) * 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = fx - x0f, wx0 = 1.0f - wx1, wy1 = fy - y0f, wy0 = 1.0f - wy1;
+        const bool vx0 = x0 >= 0 && x0 < R, vx1 = x1 >= 0 && x1 < R, vy0 = y0 >= 0 && y0 < R, vy1 = y1 >= 0 && y1 < R;
+        float sval = 0.f;
+        if (vy0 && vx0) sval += mt[y0 * R + x0] * (wy0 * wx0);
+        if (vy0 && vx1) sval += mt[y0 * R + x1] * (wy0 * wx1);
+        if (vy1 && vx0) sval += mt[y1 * R + x0] * (wy1 * wx0);
+        if (vy1 && vx1) sval += mt[y1 * R + x1] * (wy1 * wx1);
+        const float de = v - sval;
+        se += de * de;
+        const float ge = gscale * de;
+        g_eq_a[(size_t)k * RR + p] = ge;
+        float* gb = g_eq_b + (size_t)k * RR;
+        if (vy0 && vx0) atomicAdd(&gb[y0 * R + x0], -ge * (wy0 * wx0));
+        if (vy0 && vx1) atomicAdd(&gb[y0 * R + x1], -ge * (wy0 * wx1));
+        if (vy1 && vx0) atomicAdd(&gb[y1 * R + x0], -ge * (wy1 * wx0));
+        if (vy1 && vx1) atomicAdd(&gb[y1 * R + x1], -ge * (wy1 * wx1));
+    }
+    ss = skp_block_sum_256(ss, red);
+    se = skp_block_sum_256(se, red);
+    if (tid == 0) {
+        partial[(size_t)(0 * a.K + k) * a.nchunk + chunk] = ss;
+        partial[(size_t)(1 * a.K + k) * a.nchunk + chunk] = se;
+    }
+}
+
+extern "C" int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
+                                  const int32_t* argmax, int num_subjects, float sigma, const float* theta_inv,
+                                  float* partial, float* g_sharp, float* g_eq_a, float* g_eq_b, void* stream) {
+    if (!M || !Mt || !sel || !argmax || !theta_inv || !partial || !g_sharp || !g_eq_a || !g_eq_b) return SKP_E_BADARG;
+    if (K <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
+    if (num_subjects < 1 || num_subjects > SKP_MAX_SUBJECTS || K > 65535) return SKP_E_RANGE;
+    LossArgs a{};
+    a.K = K; a.T = T; a.R = R; a.S = num_subjects; a.sigma = sigma;
+    a.nchunk = (R * R + 1023) / 1024;
+    for (int i = 0; i < 6; ++i) a.th[i] = theta_inv[i];
+    hipLaunchKernelGGL(skp_losses_kernel, dim3(a.nchunk, K), dim3(256), 0, (hipStream_t)stream, M, Mt, sel, argmax, a,
+                       partial, g_sharp, g_eq_a, g_eq_b);
+    return skp_launch_status();
+}
+
+// dst[sel[k], :] += a*x[k,:] + b*y[k,:]
+__global__ __launch_bounds__(256) void skp_rows_axpy_kernel(float* __restrict__ dst, const int64_t* __restrict__ sel,
+                                                            int64_t n, const float* __restrict__ x,
+                                                            const float* __restrict__ a, const float* __restrict__ y,
+                                                            const float* __restrict__ b) {
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = a[0] * x[(size_t)k * n + i];
+    if (y) v += b[0] * y[(size_t)k * n + i];
+    dst[(size_t)sel[k] * n + i] += v;
+}
+
+extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t n, const float* x, const float* a,
+                                 const float* y, const float* b, void* stream) {
+    if (!dst || !sel || !x || !a || K <= 0 || n <= 0 || (y && !b)) return SKP_E_BADARG;
+    if (K > 65535) return SKP_E_RANGE;
+    hipLaunchKernelGGL(skp_rows_axpy_kernel, dim3((unsigned)((n + 255) / 256), K), dim3(256), 0, (hipStream_t)stream,
+                       dst, sel, n, x, a, y, b);
+    return skp_launch_status();
+}
+
+extern "C" int skp_abi_version(void) { return 1; }

@@ -1,0 +1,225 @@
+"""Torch-facing wrappers of the HIP kernels (libskp_hip.so via ctypes).
+
+PyTorch is used here only for device memory, streams and autograd bookkeeping; every op below
+launches hand-written gfx950 kernels through the C ABI of include/skp.h on torch's CURRENT
+stream.  No op has an eager/CPU fallback: a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import _native as N
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the StableKeypoints hot path runs on the HIP kernels only "
+                           f"(got a {t.device} tensor; there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# low-res logits (fp32 MFMA)                                            ptp_utils.py:483-493
+# ---------------------------------------------------------------------------------------------
+def qk_logits(q: torch.Tensor, k: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """S[b,h,t,p] = scale*log2(e) * <k[bk,t,h,:], q[b,p,h,:]>;  q [B,s2,C], k [Bk,T,C] -> [B,H,T,s2]."""
+    q, k = _dev(q, "q"), _dev(k, "k")
+    B, s2, C = q.shape
+    Bk, T, Ck = k.shape
+    if Ck != C or C % heads:
+        raise RuntimeError("qk_logits: channel mismatch")
+    S = torch.empty(B, heads, T, s2, device=q.device, dtype=torch.float32)
+    N.check(N.lib().skp_qk_logits_f32(q.data_ptr(), k.data_ptr(), S.data_ptr(), B, Bk, heads, T, s2,
+                                      C // heads, float(scale), _stream()), "skp_qk_logits_f32")
+    return S
+
+
+def _gemm_nt(A, B, Cout, M, Nn, K, Z0, Z1, sa, sb, sc, alpha):
+    N.check(N.lib().skp_gemm_nt_f32(A.data_ptr(), B.data_ptr(), Cout.data_ptr(), M, Nn, K, Z0, Z1,
+                                    *sa, *sb, *sc, float(alpha), _stream()), "skp_gemm_nt_f32")
+
+
+def _map_fwd(S: Sequence[torch.Tensor], sides: Sequence[int], B: int, H: int, T: int, R: int):
+    dev = S[0].device
+    M = torch.empty(B, T, R, R, device=dev, dtype=torch.float32)
+    lse = torch.empty(B, len(S) * H, R * R, device=dev, dtype=torch.float32)
+    sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
+    si, _k2 = N.int_array(sides)
+    N.check(N.lib().skp_attn_map_fwd_f32(sp, si, len(S), B, H, T, R, M.data_ptr(), lse.data_ptr(), _stream()),
+            "skp_attn_map_fwd_f32")
+    return M, lse
+
+
+class AttnMapFn(torch.autograd.Function):
+    """M[b,t,:,:] = mean over (layer, head) of softmax_t(bicubic_R(scale * q_l k_l^T)).
+
+    Replaces ptp_utils.py:513-538 + optimize.py:27-79 (see csrc/skp_attn_map.hip).
+    apply(R, heads, scales(tuple), q_0, k_0, q_1, k_1, ...) with q_l [B,s_l^2,C_l], k_l [Bk,T,C_l].
+    """
+
+    @staticmethod
+    def forward(ctx, R: int, heads: int, scales: Tuple[float, ...], *qk: torch.Tensor):
+        L = len(qk) // 2
+        qs = [_dev(qk[2 * i], "q") for i in range(L)]
+        ks = [_dev(qk[2 * i + 1], "k") for i in range(L)]
+        B, T = qs[0].shape[0], ks[0].shape[1]
+        sides = []
+        for q in qs:
+            s = int(round(q.shape[1] ** 0.5))
+            if s * s != q.shape[1]:
+                raise RuntimeError("AttnMapFn: query length is not a square")
+            sides.append(s)
+        S = [qk_logits(q, k, heads, sc) for q, k, sc in zip(qs, ks, scales)]
+        M, lse = _map_fwd(S, sides, B, heads, T, R)
+        ctx.save_for_backward(lse, *qs, *ks, *S)
+        ctx.meta = (R, heads, tuple(scales), tuple(sides), B, T, L)
+        return M
+
+    @staticmethod
+    def backward(ctx, dM: torch.Tensor):
+        R, H, scales, sides, B, T, L = ctx.meta
+        saved = ctx.saved_tensors
+        lse, qs, ks, S = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:]
+        dM = _dev(dM, "dM")
+        dS = [torch.zeros_like(s_) for s_ in S]
+        sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
+        dp, _k2 = N.ptr_array([t.data_ptr() for t in dS])
+        si, _k3 = N.int_array(sides)
+        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, L, B, H, T, R, dM.data_ptr(), lse.data_ptr(), _stream()),
+                "skp_attn_map_bwd_f32")
+        grads: List[torch.Tensor] = []
+        for l in range(L):
+            q, k, ds, sc = qs[l], ks[l], dS[l], scales[l]
+            s2, C = q.shape[1], q.shape[2]
+            d = C // H
+            Bk = k.shape[0]
+            dq = dk = None
+            if ctx.needs_input_grad[3 + 2 * l]:
+                dq = torch.empty_like(q)       # dq[b,p,h*d+c] = sc * sum_t dS[b,h,t,p] k[bk,t,h*d+c]
+                _gemm_nt(ds, k, dq, s2, d, T, B, H,
+                         (H * T * s2, T * s2, 1, s2), (0 if Bk == 1 else T * C, d, 1, C),
+                         (s2 * C, d, C), sc)
+            if ctx.needs_input_grad[4 + 2 * l]:
+                dkb = torch.empty(B, T, C, device=q.device, dtype=torch.float32)
+                _gemm_nt(ds, q, dkb, T, d, s2, B, H,    # dk[b,t,h*d+c] = sc * sum_p dS[b,h,t,p] q[b,p,h*d+c]
+                         (H * T * s2, T * s2, s2, 1), (s2 * C, d, 1, C), (T * C, d, C), sc)
+                dk = dkb.sum(dim=0, keepdim=True) if (Bk == 1 and B > 1) else dkb
+            grads += [dq, dk]
+        return (None, None, None, *grads)
+
+
+def attn_map(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], heads: int, scales: Sequence[float],
+             R: int) -> torch.Tensor:
+    flat = []
+    for q, k in zip(qs, ks):
+        flat += [q, k]
+    return AttnMapFn.apply(int(R), int(heads), tuple(float(s) for s in scales), *flat)
+
+
+def materialize_probs(q: torch.Tensor, k: torch.Tensor, heads: int, scale: float, R: int) -> torch.Tensor:
+    """Reference-layout tensor (B*h, R*R, T) of one hooked layer (ptp_utils.py:535-538), produced by
+    the SAME fused kernel run one head at a time (L=1, H=1).  Compatibility/testing path only."""
+    B, T = q.shape[0], k.shape[1]
+    s = int(round(q.shape[1] ** 0.5))
+    S = qk_logits(q, k, heads, scale)
+    outs = []
+    for h in range(heads):
+        Sh = S[:, h:h + 1].contiguous()
+        Mh, _ = _map_fwd([Sh], [s], B, 1, T, R)               # [B,T,R,R]
+        outs.append(Mh.reshape(B, T, R * R).permute(0, 2, 1))
+    return torch.stack(outs, dim=1).reshape(B * heads, R * R, T)
+
+
+# ---------------------------------------------------------------------------------------------
+# token statistics / selection                      eval.py:39-111, ptp_utils.py:86-159
+# ---------------------------------------------------------------------------------------------
+def token_stats(M: torch.Tensor, num_subjects: int = 1, sigma: float = 2.0, eps: float = 1e-5,
+                want_kl: bool = True):
+    """-> (argmax int32 [num_subjects, T] flat indices, kl float32 [T] or None)."""
+    M = _dev(M.detach(), "M")
+    T, R, R2 = M.shape
+    if R != R2:
+        raise RuntimeError("token_stats: map must be square")
+    am = torch.empty(num_subjects, T, device=M.device, dtype=torch.int32)
+    kl = torch.empty(T, device=M.device, dtype=torch.float32) if want_kl else None
+    N.check(N.lib().skp_token_stats_f32(M.data_ptr(), T, R, num_subjects, float(sigma), float(eps),
+                                        am.data_ptr(), kl.data_ptr() if want_kl else None, _stream()),
+            "skp_token_stats_f32")
+    return am, kl
+
+
+def select_tokens(kl: torch.Tensor, argmax_t: torch.Tensor, R: int, n_cand: int, top_k: int):
+    """-> (cand int64 [n_cand], sel int64 [top_k]); argmax_t = first-subject arg-max of the TRANSFORMED map."""
+    T = kl.shape[0]
+    cand = torch.empty(n_cand, device=kl.device, dtype=torch.int64)
+    sel = torch.empty(top_k, device=kl.device, dtype=torch.int64)
+    am = argmax_t.reshape(-1)[:T].contiguous()
+    N.check(N.lib().skp_select_tokens(kl.data_ptr(), am.data_ptr(), T, R, n_cand, top_k, cand.data_ptr(),
+                                      sel.data_ptr(), _stream()), "skp_select_tokens")
+    return cand, sel
+
+
+# ---------------------------------------------------------------------------------------------
+# losses                                             optimize.py:157-206
+# ---------------------------------------------------------------------------------------------
+def invert_affine(theta) -> List[float]:
+    """Inverse of the 2x3 affine [[a,b,tx],[c,d,ty]] (invertable_transform.py:77-84), closed form in fp64."""
+    a, b, tx, c, d, ty = [float(v) for v in theta]
+    det = a * d - b * c
+    ia, ib, ic, id_ = d / det, -b / det, -c / det, a / det
+    return [ia, ib, -(ia * tx + ib * ty), ic, id_, -(ic * tx + id_ * ty)]
+
+
+class LossesFn(torch.autograd.Function):
+    """(sharpening_loss, equivariance_loss) of optimize.py:157-206 for the selected tokens, fused with
+    their gradients.  apply(M, Mt, sel, argmax, theta_inv(6 floats), sigma, num_subjects)."""
+
+    @staticmethod
+    def forward(ctx, M, Mt, sel, argmax, theta_inv, sigma, num_subjects):
+        M, Mt = _dev(M, "M"), _dev(Mt, "Mt")
+        T, R, _ = M.shape
+        K = sel.shape[0]
+        nchunk = (R * R + 1023) // 1024
+        partial = torch.empty(2, K, nchunk, device=M.device, dtype=torch.float32)
+        g_sharp = torch.empty(K, R, R, device=M.device, dtype=torch.float32)
+        g_eq_a = torch.empty_like(g_sharp)
+        g_eq_b = torch.zeros_like(g_sharp)
+        th, _keep = N.float_array(theta_inv)
+        N.check(N.lib().skp_losses_fwd_f32(M.data_ptr(), Mt.data_ptr(), sel.data_ptr(), K, T, R, argmax.data_ptr(),
+                                           int(num_subjects), float(sigma), th, partial.data_ptr(),
+                                           g_sharp.data_ptr(), g_eq_a.data_ptr(), g_eq_b.data_ptr(), _stream()),
+                "skp_losses_fwd_f32")
+        sums = partial.sum(dim=(1, 2)) / float(K * R * R)
+        ctx.save_for_backward(sel, g_sharp, g_eq_a, g_eq_b)
+        ctx.shape = (T, R)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, go_sharp, go_equiv):
+        sel, g_sharp, g_eq_a, g_eq_b = ctx.saved_tensors
+        T, R = ctx.shape
+        dev = g_sharp.device
+        z = torch.zeros((), device=dev, dtype=torch.float32)
+        gs = z if go_sharp is None else go_sharp.reshape(()).float().contiguous()
+        ge = z if go_equiv is None else go_equiv.reshape(()).float().contiguous()
+        dM = torch.zeros(T, R, R, device=dev, dtype=torch.float32)
+        dMt = torch.zeros(T, R, R, device=dev, dtype=torch.float32)
+        K, n = sel.shape[0], R * R
+        N.check(N.lib().skp_rows_axpy_f32(dM.data_ptr(), sel.data_ptr(), K, n, g_sharp.data_ptr(), gs.data_ptr(),
+                                          g_eq_a.data_ptr(), ge.data_ptr(), _stream()), "skp_rows_axpy_f32")
+        N.check(N.lib().skp_rows_axpy_f32(dMt.data_ptr(), sel.data_ptr(), K, n, g_eq_b.data_ptr(), ge.data_ptr(),
+                                          None, None, _stream()), "skp_rows_axpy_f32")
+        return dM, dMt, None, None, None, None, None
+
+
+def fused_losses(M, Mt, sel, argmax, theta, sigma: float, num_subjects: int = 1):
+    """theta: the FORWARD 2x3 affine of this image (6 floats, row-major). -> (sharp, equiv)."""
+    return LossesFn.apply(M, Mt, sel, argmax, invert_affine(theta), float(sigma), int(num_subjects))

@@ -1,0 +1,204 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle and vs the golden vectors that were
+captured from the reference.  Tolerances: probabilities/maps rtol 1e-3 (BASELINE.json north_star)
+with atol 1e-6 for near-zero probabilities; integer outputs (arg-max, selected tokens) bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_path as R
+from oracle.fixtures import (HOOK_CASES, STACK_CASE, SEL_CASE, E2E_CASE, attention_weights, seeded,
+                             selection_maps)
+
+pytestmark = pytest.mark.gpu
+
+MAP_TOL = dict(rtol=1e-3, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from stablekeypoints_amd import ops as o
+    o.N.lib()                     # raises if libskp_hip.so is missing: no fallback
+    return o
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_gemm_nt_mfma(ops):
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K, Z0, Z1) in [(77, 256, 160, 2, 8), (33, 31, 10, 1, 3), (128, 64, 7, 1, 1), (5, 200, 80, 3, 2)]:
+        A = torch.randn(Z0, Z1, M, K, generator=g)
+        B = torch.randn(Z0, Z1, N, K, generator=g)
+        ref = torch.einsum("abmk,abnk->abmn", A.double(), B.double()) * 0.37
+        Ad, Bd = A.cuda(), B.cuda()
+        C = torch.empty(Z0, Z1, M, N, device="cuda")
+        ops._gemm_nt(Ad, Bd, C, M, N, K, Z0, Z1, (Z1 * M * K, M * K, K, 1), (Z1 * N * K, N * K, K, 1),
+                     (Z1 * M * N, M * N, N), 0.37)
+        torch.testing.assert_close(C.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    # transposed-operand form (k strided), as used by the backward products
+    M, N, K = 40, 24, 50
+    A = torch.randn(K, M, generator=g); B = torch.randn(K, N, generator=g)
+    C = torch.empty(M, N, device="cuda")
+    ops._gemm_nt(A.cuda(), B.cuda(), C, M, N, K, 1, 1, (0, 0, 1, M), (0, 0, 1, N), (0, 0, N), 1.0)
+    torch.testing.assert_close(C.cpu().double(), A.double().t() @ B.double(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(HOOK_CASES))
+def test_g1_hook_probs_vs_reference_golden(ops, golden, name):
+    g = golden("g1_hook.npz")
+    c = HOOK_CASES[name]
+    wq, wk, wv, wo, bo = attention_weights(c["C"], c["ctx_dim"], c["seed"])
+    x = seeded((c["B"], c["s"] ** 2, c["C"]), c["seed"] + 100)
+    ctx = seeded((c["B"], c["T"], c["ctx_dim"]), c["seed"] + 200)
+    q = (x @ wq.t()).cuda()
+    k = (ctx @ wk.t()).cuda()
+    scale = (c["C"] // c["heads"]) ** -0.5
+    p = ops.materialize_probs(q, k, c["heads"], scale, c["R"]).cpu()
+    assert p.shape == (c["B"] * c["heads"], c["R"] ** 2, c["T"])
+    if c["full"]:
+        torch.testing.assert_close(p, t(g[name + "/p_up"]), **MAP_TOL)
+    else:
+        torch.testing.assert_close(p.reshape(-1)[:: c["stride"]], t(g[name + "/p_up_strided"]), **MAP_TOL)
+    torch.testing.assert_close(p.sum(-1), torch.ones(p.shape[:2]), rtol=1e-5, atol=1e-5)
+
+
+def _stack_qk(case, ctx, view=0):
+    qs, ks, scales = [], [], []
+    for i, (sl, Cl) in enumerate(case["layers"]):
+        wq, wk, *_ = attention_weights(Cl, case["ctx_dim"], case["seed"] + i)
+        x = seeded((1, sl * sl, Cl), case["seed"] + 100 + 10 * view + i)
+        qs.append((x @ wq.t()).cuda())
+        ks.append(ctx @ wk.t().to(ctx.device))
+        scales.append((Cl // case["heads"]) ** -0.5)
+    return qs, ks, scales
+
+
+def test_g2_fused_map_vs_reference_collect_maps(ops, golden):
+    g = golden("g2_collect_maps.npz")
+    c = STACK_CASE
+    ctx = seeded((1, c["T"], c["ctx_dim"]), c["seed"] + 200).cuda()
+    qs, ks, scales = _stack_qk(c, ctx)
+    M = ops.attn_map(qs, ks, c["heads"], scales, c["R"])[0].cpu()
+    torch.testing.assert_close(M, t(g["res-1"]), **MAP_TOL)
+    M02 = ops.attn_map([qs[0], qs[2]], [ks[0], ks[2]], c["heads"], [scales[0], scales[2]], c["R"])[0].cpu()
+    torch.testing.assert_close(M02, t(g["res-1_layers02"]), **MAP_TOL)
+    torch.testing.assert_close(M.sum(0), torch.ones(c["R"], c["R"]), rtol=1e-5, atol=1e-5)
+
+
+def test_attn_map_backward_vs_oracle_autograd(ops):
+    """d(sum(M*W))/d(q,k) of the fused op vs fp64 autograd through the reference formulation."""
+    c = STACK_CASE
+    heads, Rr, T = c["heads"], c["R"], c["T"]
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    qs = [torch.randn(B, sl * sl, Cl, generator=g) for sl, Cl in c["layers"]]
+    ks = [torch.randn(1, T, Cl, generator=g) for sl, Cl in c["layers"]]
+    W = torch.randn(B, T, Rr, Rr, generator=g)
+    scales = [(Cl // heads) ** -0.5 for _, Cl in c["layers"]]
+    # oracle (fp64): upsample q (not logits), per-head softmax, mean -- the reference's order of ops
+    qd = [q.double().requires_grad_(True) for q in qs]
+    kd = [k.double().requires_grad_(True) for k in ks]
+    maps = []
+    for q, k, (sl, Cl), sc in zip(qd, kd, c["layers"], scales):
+        qi = q.reshape(B, sl, sl, Cl).permute(0, 3, 1, 2)
+        qu = torch.nn.functional.interpolate(qi, size=(Rr, Rr), mode="bicubic", align_corners=False)
+        qu = R.split_heads(qu.permute(0, 2, 3, 1).reshape(B, Rr * Rr, Cl), heads)
+        kk = R.split_heads(k.expand(B, -1, -1), heads)
+        p = (torch.einsum("bid,bjd->bij", qu, kk) * sc).softmax(-1)          # (B*h, R2, T)
+        maps.append(p.reshape(B, heads, Rr, Rr, T).permute(0, 1, 4, 2, 3))
+    Mref = torch.stack(maps, 0).mean(dim=(0, 2))                              # [B,T,R,R]
+    (Mref * W.double()).sum().backward()
+    qg = [q.cuda().requires_grad_(True) for q in qs]
+    kg = [k.cuda().requires_grad_(True) for k in ks]
+    M = ops.attn_map(qg, kg, heads, scales, Rr)
+    torch.testing.assert_close(M.detach().cpu().double(), Mref.detach(), rtol=1e-3, atol=1e-6)
+    (M * W.cuda()).sum().backward()
+    for a, b in zip(qg + kg, qd + kd):
+        ref = b.grad
+        torch.testing.assert_close(a.grad.cpu().double(), ref, rtol=2e-3, atol=2e-5 * ref.abs().max().item())
+
+
+def test_g3_token_stats_and_selection(ops, golden):
+    g = golden("g3_selection.npz")
+    s = SEL_CASE
+    maps, maps_t = selection_maps()
+    md, mtd = maps.cuda(), maps_t.cuda()
+    Rr = s["R"]
+    for ns in (1, 2):
+        am, kl = ops.token_stats(md, num_subjects=ns, sigma=s["sigma"])
+        ref_pts = t(g[f"find_k_max_pixels_{ns}"])                              # [ns, T, 2] (row+.5, col+.5)
+        ref_flat = ((ref_pts[..., 0] - 0.5) * Rr + (ref_pts[..., 1] - 0.5)).long()
+        assert torch.equal(am.cpu().long(), ref_flat)
+        torch.testing.assert_close(kl.cpu(), t(g[f"kl_ns{ns}"]), rtol=2e-5, atol=1e-6)
+        am_t, _ = ops.token_stats(mtd, num_subjects=1, sigma=s["sigma"], want_kl=False)
+        cand, sel = ops.select_tokens(kl, am_t[0], Rr, s["n_cand"], s["top_k"])
+        assert torch.equal(cand.cpu(), t(g[f"top_k_gaussian_ns{ns}"]))
+        assert torch.equal(sel.cpu(), t(g[f"fps_ns{ns}"]))
+    assert am[0, 5].item() == 3 * Rr + 4                                        # first index wins the tie
+
+
+def test_g4_losses_and_gradients(ops, golden):
+    g = golden("g4_losses.npz")
+    s = SEL_CASE
+    maps, maps_t = selection_maps()
+    sel = torch.tensor(s["sel"]).cuda()
+    thetas = t(g["theta"])
+    for ns in (1, 2):
+        for index in (0, 1):
+            a = maps.cuda().requires_grad_(True)
+            b = maps_t.cuda().requires_grad_(True)
+            am, _ = ops.token_stats(a, num_subjects=ns, sigma=s["sigma"], want_kl=False)
+            sharp, equiv = ops.fused_losses(a, b, sel, am, thetas[index].reshape(-1).tolist(), s["sigma"], ns)
+            assert abs(sharp.item() - float(g[f"sharp_ns{ns}"])) < 1e-5 * abs(float(g[f"sharp_ns{ns}"]))
+            assert abs(equiv.item() - float(g[f"equiv_{index}"])) < 1e-4 * abs(float(g[f"equiv_{index}"]))
+            (sharp * 3.0 + equiv * 7.0).backward()
+            ga = 3.0 * t(g[f"sharp_grad_ns{ns}"]) + 7.0 * t(g[f"equiv_grad_a_{index}"])
+            gb = 7.0 * t(g[f"equiv_grad_b_{index}"])
+            torch.testing.assert_close(a.grad[sel].cpu(), ga, rtol=1e-4, atol=2e-5 * ga.abs().max().item())
+            torch.testing.assert_close(b.grad[sel].cpu(), gb, rtol=1e-3, atol=2e-5 * gb.abs().max().item())
+            mask = torch.ones(maps.shape[0], dtype=torch.bool); mask[sel.cpu()] = False
+            assert a.grad.cpu()[mask].abs().max().item() == 0.0
+
+
+def test_g5_subgraph_gradient_vs_reference(ops, golden):
+    """Two views -> fused maps -> on-device selection -> fused losses -> d/d context (through to_k)."""
+    g = golden("g5_subgraph.npz")
+    e = E2E_CASE
+    context = seeded((1, e["T"], e["ctx_dim"]), e["seed"] + 200).cuda().requires_grad_(True)
+    maps = []
+    for view in (0, 1):
+        qs, ks, scales = _stack_qk(e, context, view=view)
+        maps.append(ops.attn_map(qs, ks, e["heads"], scales, e["R"])[0])
+    am, am_t = maps
+    torch.testing.assert_close(am.detach().cpu(), t(g["map"]), **MAP_TOL)
+    torch.testing.assert_close(am_t.detach().cpu(), t(g["map_t"]), **MAP_TOL)
+    st, kl = ops.token_stats(am, 1, e["sigma"])
+    st_t, _ = ops.token_stats(am_t, 1, e["sigma"], want_kl=False)
+    cand, sel = ops.select_tokens(kl, st_t[0], e["R"], e["n_cand"], e["top_k"])
+    assert torch.equal(cand.cpu(), t(g["cand"]))
+    assert torch.equal(sel.cpu(), t(g["sel"]))
+    theta = R.affine_matrix(11.0, 0.87, (0.13, -0.21)).reshape(-1).tolist()
+    sharp, equiv = ops.fused_losses(am, am_t, sel, st, theta, e["sigma"], 1)
+    assert abs(sharp.item() - float(g["sharp"])) < 1e-4 * abs(float(g["sharp"]))
+    assert abs(equiv.item() - float(g["equiv"])) < 1e-3 * abs(float(g["equiv"]))
+    (equiv * 1000.0 + sharp * 100.0).backward()
+    ref = t(g["context_grad"])
+    torch.testing.assert_close(context.grad.cpu(), ref, rtol=2e-3, atol=2e-5 * ref.abs().max().item())
+
+
+def test_sd_shape_maps_invariants(ops):
+    """BASELINE config-2 shapes (3x(16^2,C=1280) + 1x(32^2,C=640), T=77, R=128, 8 heads): size-independent
+    properties -- probabilities sum to 1 over tokens; batch rows are independent; T=100 path."""
+    gen = torch.Generator().manual_seed(3)
+    for T in (77, 100):
+        B = 2
+        qs = [torch.randn(B, 256, 1280, generator=gen).cuda() for _ in range(3)] + [torch.randn(B, 1024, 640, generator=gen).cuda()]
+        ks = [torch.randn(1, T, 1280, generator=gen).cuda() for _ in range(3)] + [torch.randn(1, T, 640, generator=gen).cuda()]
+        scales = [160 ** -0.5] * 3 + [80 ** -0.5]
+        M = ops.attn_map(qs, ks, 8, scales, 128)
+        assert M.shape == (B, T, 128, 128)
+        torch.testing.assert_close(M.sum(1), torch.ones(B, 128, 128, device="cuda"), rtol=1e-5, atol=1e-5)
+        M1 = ops.attn_map([q[1:2] for q in qs], ks, 8, scales, 128)
+        torch.testing.assert_close(M1[0], M[1], rtol=0, atol=0)
