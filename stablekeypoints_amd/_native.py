@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has to bind to the HIP runtime
+#                              that PyTorch-ROCm already loaded (one runtime per process, shared streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
 ABI_VERSION = 1

@@ -1,0 +1,200 @@
+"""Token optimisation loop and losses, reference API of optimize.py (collect_maps, sharpening_loss,
+equivariance_loss, find_gaussian_loss_at_point, optimize_embedding).
+
+`optimize_embedding` keeps the reference's signature and per-optimizer-step semantics
+(optimize.py:269-452) but is laid out for one MI355X per process:
+  * the image and its affine copy go through the VAE/UNet as ONE batch, and all images of an
+    accumulation group are batched together (the frozen network sees B = 2*images rows; the
+    gradient of the shared embedding sums over rows, which is exactly what the reference's
+    accumulation loop + `.repeat` backward compute, optimize.py:420-425, ptp_utils.py:229);
+  * the forward stops after the 4th hooked layer (result-identical);
+  * maps, arg-max, KL ranking, furthest-point sampling and both losses run in HIP kernels with no
+    host synchronisation; the only collective is one all-reduce of the [1,T,768] gradient per step.
+"""
+from __future__ import annotations
+
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import dist as skp_dist
+from . import ops, ptp_utils
+from ._maps import collect_maps, collect_maps_batched          # noqa: F401  (collect_maps is public API)
+from .eval import find_k_max_pixels
+from .invertable_transform import RandomAffineWithInverse
+from .optimize_token import gaussian_circles
+
+
+# ---------------------------------------------------------------------------------------------
+# losses, reference-shaped API                                         optimize.py:157-206
+# ---------------------------------------------------------------------------------------------
+def _all_rows(n, device):
+    return torch.arange(n, device=device, dtype=torch.int64)
+
+
+def sharpening_loss(attn_map, sigma=1.0, temperature=1e1, device="cuda", num_subjects=1):
+    """optimize.py:166-179 on the fused loss kernel (identity affine => the equivariance term is unused)."""
+    am, _ = ops.token_stats(attn_map, num_subjects=num_subjects, sigma=sigma, want_kl=False)
+    sharp, _ = ops.fused_losses(attn_map, attn_map, _all_rows(attn_map.shape[0], attn_map.device), am,
+                                [1, 0, 0, 0, 1, 0], sigma, num_subjects)
+    return sharp
+
+
+def find_gaussian_loss_at_point(attn_map, pos, sigma=1.0, temperature=1e-1, device="cuda", indices=None,
+                                num_subjects=1):
+    """optimize.py:182-206 for caller-supplied positions (torch ops; not on the optimisation path)."""
+    target = gaussian_circles(pos, size=attn_map.shape[1], sigma=sigma).to(attn_map.device)
+    if indices is not None:
+        attn_map, target = attn_map[indices], target[indices]
+    return F.mse_loss(attn_map, target)
+
+
+def equivariance_loss(embeddings_initial, embeddings_transformed, transform, index):
+    """optimize.py:157-163: MSE(map, unwarp(map_T)[index]) with transform.last_params['theta'][index]."""
+    theta = transform.last_params["theta"][index].reshape(-1).tolist()
+    mt = embeddings_transformed[index] if embeddings_transformed.dim() == 4 else embeddings_transformed
+    k = embeddings_initial.shape[0]
+    am = torch.zeros(1, k, device=embeddings_initial.device, dtype=torch.int32)
+    _, equiv = ops.fused_losses(embeddings_initial, mt, _all_rows(k, embeddings_initial.device), am, theta, 1.0, 1)
+    return equiv
+
+
+# ---------------------------------------------------------------------------------------------
+# datasets: only the {'img': float[3,H,W] in [0,1]} contract matters on this path
+# ---------------------------------------------------------------------------------------------
+class SyntheticImages(torch.utils.data.Dataset):
+    """`torch.rand(N,3,S,S)` under a fixed seed (SURVEY.md 8(d) synthetic inputs), resident on `device`."""
+
+    def __init__(self, n=64, size=512, seed=0, device="cpu"):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.data = torch.rand(n, 3, size, size, generator=g).to(device)
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, i):
+        return {"img": self.data[i]}
+
+
+def build_dataset(args):
+    name = getattr(args, "dataset_name", "synthetic")
+    if name == "synthetic":
+        return SyntheticImages(n=getattr(args, "max_len", -1) if getattr(args, "max_len", -1) > 0 else 64,
+                               size=getattr(args, "image_size", 512), seed=getattr(args, "seed", 0),
+                               device=getattr(args, "device", "cpu"))
+    if name == "custom":
+        from .custom_images import CustomDataset
+        return CustomDataset(data_root=args.dataset_loc, image_size=getattr(args, "image_size", 512))
+    raise NotImplementedError(f"dataset '{name}' is outside the hot-path scope (SURVEY.md 2.1 row 15); "
+                              "use 'synthetic' or 'custom'")
+
+
+# ---------------------------------------------------------------------------------------------
+# one accumulation group on this rank
+# ---------------------------------------------------------------------------------------------
+def image_losses(attn_map, attn_map_t, theta_row, args):
+    """optimize.py:380-414 for one image, entirely on device: -> (sharp, equiv, selected tokens)."""
+    sigma, ns = args.sigma, getattr(args, "num_subjects", 1)
+    strategy = getattr(args, "top_k_strategy", "gaussian")
+    am, kl = ops.token_stats(attn_map, num_subjects=ns, sigma=sigma, want_kl=(strategy == "gaussian"))
+    am_t, _ = ops.token_stats(attn_map_t, num_subjects=1, sigma=sigma, want_kl=False)
+    if strategy == "gaussian":
+        order = kl
+    elif strategy == "consistent":
+        order = torch.arange(attn_map.shape[0], device=attn_map.device, dtype=torch.float32)
+    else:
+        raise NotImplementedError(strategy)
+    n_cand = min(args.furthest_point_num_samples, attn_map.shape[0])
+    _, sel = ops.select_tokens(order, am_t[0], attn_map.shape[-1], n_cand, args.top_k)
+    sharp, equiv = ops.fused_losses(attn_map, attn_map_t, sel, am, theta_row, sigma, ns)
+    return sharp, equiv, sel
+
+
+def group_step(ldm, images, context, args, controller, transform, denom, noise=None, thetas=None):
+    """Forward both views of `images` [n,3,H,W] as one batch, losses per image, backward of
+    sum_i (w_e*equiv_i + w_s*sharp_i)/denom into `context.grad`.  Returns detached (total, equiv, sharp)."""
+    n = images.shape[0]
+    dev = context.device
+    images = images.to(dev)
+    warped = transform(images, theta=thetas)                     # draws n thetas (4 uniforms each) unless given
+    thetas = transform.last_params["theta"].detach().cpu()
+    both = torch.cat([images, warped], dim=0)
+    ptp_utils.find_pred_noise(ldm, both, context, noise_level=args.noise_level, device=dev, noise=noise,
+                              early_exit=True, controllers={dev: controller})
+    maps = collect_maps_batched(controller, layers=args.layers)  # [2n,T,R,R]
+    tot_e = torch.zeros((), device=dev)
+    tot_s = torch.zeros((), device=dev)
+    for i in range(n):
+        sharp, equiv, _ = image_losses(maps[i], maps[n + i], thetas[i].reshape(-1).tolist(), args)
+        tot_e = tot_e + equiv
+        tot_s = tot_s + sharp
+    loss = (tot_e * args.equivariance_attn_loss_weight + tot_s * args.sharpening_loss_weight) / denom
+    loss.backward()
+    return loss.detach(), tot_e.detach() / denom, tot_s.detach() / denom
+
+
+def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
+                       from_where=["down_cross", "mid_cross", "up_cross"]):
+    """Reference signature (optimize.py:269-276).  `num_gpus` = devices driven by THIS process (1); the
+    data-parallel width is `num_gpus * world_size`.  Returns the detached embedding [1,T,768]."""
+    world, rank = skp_dist.world_size(), skp_dist.rank()
+    width = num_gpus * world
+    if args.batch_size < width or args.batch_size % width:
+        raise ValueError(f"batch_size ({args.batch_size}) must be a positive multiple of the data-parallel "
+                         f"width ({width}) -- the reference divides by batch_size//num_gpus (optimize.py:339)")
+    accum = args.batch_size // width                              # images per rank per optimizer step
+    dev, controller = next(iter(controllers.items()))
+    dataset = build_dataset(args)
+    transform = RandomAffineWithInverse(degrees=args.augment_degrees, scale=args.augment_scale,
+                                        translate=args.augment_translate)
+    if context is None:
+        context = ptp_utils.init_random_noise(args.device, num_words=args.num_tokens)
+    context = context.to(dev)
+    context.requires_grad = True
+    optimizer = torch.optim.Adam([context], lr=args.lr)
+    reducer = skp_dist.EmbeddingReducer(context, optimizer)
+    group = max(1, min(accum, getattr(args, "images_per_forward", accum)))
+    shuffle_gen = torch.Generator(device="cpu").manual_seed(getattr(args, "seed", 0) + 1234)
+    order, cursor = [], 0
+    log_every = getattr(args, "log_interval", 50)
+    start = it_start = time.time()
+    for step in range(int(args.num_steps)):
+        running = torch.zeros(3, device=dev)
+        done = 0
+        while done < accum:
+            n = min(group, accum - done)
+            idx = []
+            while len(idx) < n:                                  # epoch-wise shuffled, rank-sharded indices
+                if cursor >= len(order):
+                    perm = torch.randperm(len(dataset), generator=shuffle_gen).tolist()
+                    order, cursor = skp_dist.shard_indices(perm, rank, world), 0
+                    if not order:
+                        raise ValueError("dataset smaller than the data-parallel width")
+                idx.append(order[cursor]); cursor += 1
+            images = torch.stack([dataset[i]["img"] for i in idx])
+            running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size))
+            done += n
+        reducer.step()
+        if log_every and (step + 1) % log_every == 0 and rank == 0:
+            r = running.tolist()
+            print(f"step {step + 1}: loss {r[0]:.6f} equivariance {r[1] * args.equivariance_attn_loss_weight:.6f} "
+                  f"sharpening {r[2] * args.sharpening_loss_weight:.6f} "
+                  f"({(time.time() - it_start) / log_every:.3f} s/step on rank 0)", flush=True)
+            it_start = time.time()
+    if rank == 0:
+        print(f"optimization took {time.time() - start} seconds")
+    return context.detach()
+
+
+def default_args(**over):
+    """The reference CLI defaults that matter on this path (main.py:22-195)."""
+    a = dict(dataset_name="synthetic", dataset_loc="", max_len=-1, device="cuda:0", lr=5e-3, num_steps=500,
+             num_tokens=500, feature_upsample_res=128, batch_size=4, top_k_strategy="gaussian",
+             furthest_point_num_samples=25, top_k=10, num_subjects=1, sharpening_loss_weight=100,
+             equivariance_attn_loss_weight=1000, layers=[0, 1, 2, 3], noise_level=-1, sigma=2.0,
+             augment_degrees=15, augment_scale=[0.8, 1.0], augment_translate=[0.25, 0.25], wandb=False,
+             model_type="sd-legacy/stable-diffusion-v1-5", seed=0, image_size=512, log_interval=50)
+    a.update(over)
+    return SimpleNamespace(**a)

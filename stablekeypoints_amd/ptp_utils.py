@@ -1,0 +1,242 @@
+"""Attention plumbing with the reference's API (ptp_utils.py) on the MI355X kernels.
+
+Kept names/signatures: `AttentionControl`, `AttentionStore`,
+`register_attention_control`, `find_pred_noise`, `run_and_find_attn`, `image2latent`,
+`find_top_k_gaussian`, `furthest_point_sampling`, `init_random_noise`.
+
+What changes under the hood
+  * the hooked cross-attention does NOT up-sample the layer input, re-project it and materialise a
+    (B*h, R^2, T) tensor per layer (ptp_utils.py:513-538).  It records a light `FusedAttn` handle
+    (q = to_q(x) which the ordinary attention needs anyway, k = to_k(context)); `collect_maps`
+    turns all handles into the reduced [T,R,R] map with ONE fused HIP kernel
+    (csrc/skp_attn_map.hip).  `AttentionStore.step_store["attn"]` still is a list whose length is
+    the gate the patcher reads (ptp_utils.py:511); `FusedAttn.materialize()` yields the reference's
+    tensor on demand (compat / tests);
+  * token selection never leaves the device (no `.item()`), see csrc/skp_select_loss.hip.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .ldm.unet import StopForward
+from ._maps import FusedAttn, collect_maps
+
+
+# ---------------------------------------------------------------------------------------------
+# controllers                                                       reference ptp_utils.py:32-83
+# ---------------------------------------------------------------------------------------------
+class AttentionControl(abc.ABC):
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    @property
+    def num_uncond_att_layers(self):
+        return 0
+
+    @abc.abstractmethod
+    def forward(self, dict, is_cross: bool, place_in_unet: str):
+        raise NotImplementedError
+
+    def __call__(self, dict, is_cross: bool, place_in_unet: str):
+        dict = self.forward(dict, is_cross, place_in_unet)
+        return dict["attn"]
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+    def __init__(self):
+        self.cur_step = 0
+        self.num_att_layers = -1
+        self.cur_att_layer = 0
+
+
+class AttentionStore(AttentionControl):
+    """`step_store["attn"]` holds one entry per hooked layer: a `FusedAttn` handle (default) or, with
+    `materialize=True`, the reference-layout tensor (B*h, R^2, T)."""
+
+    @staticmethod
+    def get_empty_store():
+        return {"attn": []}
+
+    def forward(self, dict, is_cross: bool, place_in_unet: str):
+        self.step_store["attn"].append(dict["attn"])
+        return dict
+
+    def reset(self):
+        super(AttentionStore, self).reset()
+        self.step_store = self.get_empty_store()
+
+    def __init__(self, materialize: bool = False):
+        super(AttentionStore, self).__init__()
+        self.step_store = self.get_empty_store()
+        self.materialize = materialize
+        self.stop_after: Optional[int] = None      # early exit once this many maps are stored
+
+
+MAX_STORED_LAYERS = 4          # ptp_utils.py:511
+MAX_STORED_SEQ = 32 ** 2       # ptp_utils.py:510
+
+
+def _attention_core(module, q, k, v):
+    """softmax(scale q k^T) v per head (ptp_utils.py:493-506) on [B,N,C]/[B,T,C] tensors."""
+    fused = getattr(module, "_skp_fused_core", None)
+    if fused is not None:
+        return fused(q, k, v, module.heads, module.scale)
+    qh = module.reshape_heads_to_batch_dim(q)
+    kh = module.reshape_heads_to_batch_dim(k)
+    vh = module.reshape_heads_to_batch_dim(v)
+    attn = torch.baddbmm(torch.empty(qh.shape[0], qh.shape[1], kh.shape[1], dtype=q.dtype, device=q.device),
+                         qh, kh.transpose(1, 2), beta=0, alpha=module.scale).softmax(dim=-1)
+    return module.reshape_batch_dim_to_heads(torch.bmm(attn, vh))
+
+
+def register_attention_control(model, controller, feature_upsample_res=256):
+    """Same contract as ptp_utils.py:472-573: patches `.forward` of every module whose class is named
+    `CrossAttention` under top-level children whose name contains "up", sets
+    `controller.num_att_layers`, asserts that at least one layer was found."""
+
+    def ca_forward(self, place_in_unet):
+        to_out = self.to_out[0] if isinstance(self.to_out, torch.nn.ModuleList) else self.to_out
+
+        def forward(x, context=None, mask=None):
+            if mask is not None:
+                raise NotImplementedError("attention masks are never used on this path (ptp_utils.py:496)")
+            batch_size, sequence_length, dim = x.shape
+            is_cross = context is not None
+            q = self.to_q(x)
+            ctx = context if is_cross else x
+            k = self.to_k(ctx)
+            v = self.to_v(ctx)
+            out = _attention_core(self, q, k, v)
+            if (is_cross and sequence_length <= MAX_STORED_SEQ
+                    and len(controller.step_store["attn"]) < MAX_STORED_LAYERS):
+                rec = FusedAttn(q, k, self.heads, self.scale, feature_upsample_res)
+                if getattr(controller, "materialize", False):
+                    rec = rec.materialize()
+                controller({"attn": rec}, is_cross, place_in_unet)
+                stop = getattr(controller, "stop_after", None)
+                if stop is not None and len(controller.step_store["attn"]) >= stop:
+                    raise StopForward()
+            return to_out(out)
+
+        return forward
+
+    class DummyController:
+        def __call__(self, *args):
+            return args[0]
+
+        def __init__(self):
+            self.num_att_layers = 0
+            self.step_store = {"attn": []}
+
+    if controller is None:
+        controller = DummyController()
+
+    def register_recr(net_, count, place_in_unet):
+        if net_.__class__.__name__ == "CrossAttention":
+            net_.forward = ca_forward(net_, place_in_unet)
+            return count + 1
+        elif hasattr(net_, "children"):
+            for net__ in net_.children():
+                count = register_recr(net__, count, place_in_unet)
+        return count
+
+    cross_att_count = 0
+    for name, child in model.named_children():
+        if "up" in name:
+            cross_att_count += register_recr(child, 0, "up")
+    controller.num_att_layers = cross_att_count
+    assert cross_att_count != 0, ("No cross attention layers found in the model. The module tree must use the "
+                                  "diffusers==0.8.0 `CrossAttention` layout.")
+
+
+# ---------------------------------------------------------------------------------------------
+# noised forward driver                                    reference ptp_utils.py:205-304
+# ---------------------------------------------------------------------------------------------
+def image2latent(model, image, device):
+    """ptp_utils.py:289-304: [0,1] image -> *2-1 -> VAE posterior mean * 0.18215.  Accepts the reference's
+    numpy NHWC array or a [B,3,H,W] tensor (no CPU round trip for tensors)."""
+    with torch.no_grad():
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(image).float().permute(0, 3, 1, 2)
+        image = image.to(device=device, dtype=torch.float32) * 2 - 1
+        vae = model.vae.module if isinstance(model.vae, torch.nn.DataParallel) else model.vae
+        latents = vae.encode(image)["latent_dist"].mean
+        return latents * 0.18215
+
+
+def find_pred_noise(ldm, image, context, noise_level=-1, device="cuda", noise=None, early_exit=False,
+                    controllers=None):
+    """ptp_utils.py:205-231.  `noise` lets a caller inject the gaussian (the reference draws it from the
+    device RNG, :219).  `early_exit` stops the UNet after the last stored map -- result-identical for
+    `run_and_find_attn`, which discards the prediction (ptp_utils.py:246)."""
+    if isinstance(image, torch.Tensor) and image.dim() == 3:
+        image = image[None]
+    latent = image2latent(ldm, image, device)
+    if noise is None:
+        noise = torch.randn_like(latent)
+    t = ldm.scheduler.timesteps[noise_level]
+    noisy_image = ldm.scheduler.add_noise(latent, noise, t)
+    b = noisy_image.shape[0]
+    if early_exit and controllers is not None:
+        for c in controllers.values():
+            c.stop_after = MAX_STORED_LAYERS
+    try:
+        pred_noise = ldm.unet(noisy_image, t.repeat(b), context.expand(b, -1, -1) if context.shape[0] == 1 else context)["sample"]
+    except StopForward:
+        pred_noise = None
+    finally:
+        if early_exit and controllers is not None:
+            for c in controllers.values():
+                c.stop_after = None
+    return noise, pred_noise
+
+
+def run_and_find_attn(ldm, image, context, noise_level=-1, device="cuda",
+                      from_where=["down_cross", "mid_cross", "up_cross"], layers=[0, 1, 2, 3, 4, 5],
+                      upsample_res=32, indices=None, controllers=None, noise=None, early_exit=True):
+    """ptp_utils.py:234-272: one noised UNet forward, then `collect_maps` per controller."""
+    find_pred_noise(ldm, image, context, noise_level=noise_level, device=device, noise=noise,
+                    early_exit=early_exit, controllers=controllers)
+    attention_maps = []
+    for controller in controllers:
+        attention_maps.append(collect_maps(controllers[controller], from_where=from_where,
+                                           upsample_res=upsample_res, layers=layers, indices=indices))
+        controllers[controller].reset()
+    return attention_maps
+
+
+# ---------------------------------------------------------------------------------------------
+# token selection                                              reference ptp_utils.py:86-159
+# ---------------------------------------------------------------------------------------------
+def find_top_k_gaussian(attention_maps, top_k, sigma=3, epsilon=1e-5, num_subjects=1):
+    """ptp_utils.py:86-112 -> int64[top_k] (device)."""
+    am, kl = ops.token_stats(attention_maps, num_subjects=num_subjects, sigma=sigma, eps=epsilon)
+    n = attention_maps.shape[0]
+    top_k = min(int(top_k), n)
+    cand, _ = ops.select_tokens(kl, am[0], attention_maps.shape[-1], max(top_k, 2), 2)
+    return cand[:top_k]
+
+
+def furthest_point_sampling(attention_maps, top_k, top_initial_candidates):
+    """ptp_utils.py:115-159 -> int64[top_k] (device); greedy max-min over the candidates' arg-max pixels."""
+    am, _ = ops.token_stats(attention_maps, num_subjects=1, want_kl=False)
+    n = attention_maps.shape[0]
+    cand = torch.as_tensor(top_initial_candidates, device=attention_maps.device).long()
+    order = torch.full((n,), float("inf"), device=attention_maps.device)
+    order[cand] = torch.arange(cand.numel(), device=attention_maps.device, dtype=torch.float32)
+    _, sel = ops.select_tokens(order, am[0], attention_maps.shape[-1], int(cand.numel()), int(top_k))
+    return sel
+
+
+def init_random_noise(device, num_words=77):
+    return torch.randn(1, num_words, 768).to(device)

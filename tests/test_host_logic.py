@@ -1,0 +1,159 @@
+"""CPU tests of the host side: API surface, module-tree contract, C-ABI exports, layout rules."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from stablekeypoints_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "skp.h")).read()
+    declared = sorted(set(re.findall(r"^int\s+(skp_\w+)\s*\(", hdr, flags=re.M)))
+    assert len(declared) >= 9
+    lib = N.lib()                                   # dlopen works without a GPU
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/skp.h but not exported"
+        assert name in N.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.skp_abi_version() == N.ABI_VERSION
+    # argument validation happens before any launch
+    assert lib.skp_token_stats_f32(None, 0, 0, 1, 1.0, 1e-5, None, None, None) == -1
+
+
+def test_product_never_imports_oracle_and_has_no_cpu_fallback():
+    pkg = os.path.join(ROOT, "stablekeypoints_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports oracle/"
+    from stablekeypoints_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.token_stats(torch.rand(3, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.qk_logits(torch.rand(1, 16, 8), torch.rand(1, 3, 8), 2, 0.5)
+
+
+def test_no_reference_source_in_repo():
+    assert not os.path.exists(os.path.join(ROOT, "unsupervised_keypoints"))
+    out = subprocess.run(["git", "-C", ROOT, "ls-files"], capture_output=True, text=True).stdout.split()
+    assert not [f for f in out if f.endswith((".so", ".o"))], "built artefacts must stay out of history"
+
+
+def test_sd15_module_tree_contract():
+    """The reference's name-based patcher must find 18 CrossAttention modules in up_blocks (9 self + 9
+    cross) and state-dict keys must match the 0.8.0 checkpoint layout."""
+    from stablekeypoints_amd.ldm.unet import UNet2DConditionModel
+    from stablekeypoints_amd import ptp_utils
+    with torch.device("meta"):
+        unet = UNet2DConditionModel()
+    assert sum(p.numel() for p in unet.parameters()) == 859_520_964          # SD-1.x UNet
+    keys = dict(unet.state_dict())
+    assert tuple(keys["up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k.weight"].shape) == (1280, 768)
+    assert tuple(keys["up_blocks.2.attentions.0.transformer_blocks.0.attn2.to_q.weight"].shape) == (640, 640)
+    assert tuple(keys["up_blocks.3.resnets.0.conv1.weight"].shape) == (320, 960, 3, 3)
+    assert tuple(keys["down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight"].shape) == (2560, 320)
+    assert "up_blocks.0.attentions.0.norm.weight" not in keys                   # UpBlock2D has no attention
+    ctrl = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(unet, ctrl, feature_upsample_res=128)
+    assert ctrl.num_att_layers == 18
+    patched = [n for n, m in unet.named_modules() if m.__class__.__name__ == "CrossAttention" and "forward" in m.__dict__]
+    assert len(patched) == 18 and all(n.startswith("up_blocks") for n in patched)
+    heads = {n: m.heads for n, m in unet.named_modules() if m.__class__.__name__ == "CrossAttention"}
+    assert set(heads.values()) == {8}
+    with pytest.raises(AssertionError, match="No cross attention"):
+        ptp_utils.register_attention_control(torch.nn.Sequential(torch.nn.Linear(2, 2)), ptp_utils.AttentionStore())
+
+
+@pytest.fixture(scope="module")
+def tiny_ldm():
+    from stablekeypoints_amd.optimize_token import load_ldm
+    return load_ldm("cpu", "tiny", feature_upsample_res=32)
+
+
+def test_hook_gate_handles_and_early_exit(tiny_ldm):
+    """First 4 cross layers with seq <= 32^2 are recorded (ptp_utils.py:508-512) as FusedAttn handles; the
+    early exit leaves the same store; the map reduction itself refuses to run off-GPU."""
+    from stablekeypoints_amd import ptp_utils
+    from stablekeypoints_amd._maps import FusedAttn, collect_maps
+    ldm, controllers, n = tiny_ldm
+    assert n == 1 and list(controllers) == [torch.device("cpu")]
+    ctrl = controllers[torch.device("cpu")]
+    assert ctrl.num_att_layers == 18
+    assert not any(p.requires_grad for p in ldm.unet.parameters())
+    ctx = torch.randn(1, 9, 768, requires_grad=True)
+    img = torch.rand(2, 3, 128, 128)
+    for early in (False, True):
+        ctrl.reset()
+        noise, pred = ptp_utils.find_pred_noise(ldm, img, ctx, device="cpu", early_exit=early, controllers=controllers)
+        recs = ctrl.step_store["attn"]
+        assert len(recs) == 4 and all(isinstance(r, FusedAttn) for r in recs)
+        assert [r.q.shape[1] for r in recs] == [16, 16, 16, 64]             # 3x(4x4) then 8x8 at a 16^2 latent
+        assert [r.shape for r in recs] == [(2 * 4, 32 * 32, 9)] * 4
+        assert all(r.k.requires_grad for r in recs)
+        assert (pred is None) == early and ctrl.stop_after is None
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        collect_maps(ctrl, upsample_res=-1)
+    ctrl.reset()
+    assert ctrl.step_store == {"attn": []} and ctrl.cur_att_layer == 0
+
+
+def test_attention_store_api_surface():
+    from stablekeypoints_amd.ptp_utils import AttentionControl, AttentionStore
+    s = AttentionStore()
+    assert isinstance(s, AttentionControl) and AttentionStore.get_empty_store() == {"attn": []}
+    assert s.num_att_layers == -1 and s.cur_step == 0 and s.num_uncond_att_layers == 0
+    x = object()
+    assert s({"attn": x}, True, "up") is x and s.step_store["attn"] == [x]
+    assert s.step_callback(3) == 3 and s.between_steps() is None
+    s.reset()
+    assert s.step_store["attn"] == []
+    with pytest.raises(TypeError):
+        AttentionControl()
+
+
+def test_affine_transform_matches_reference_golden(golden):
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from oracle.fixtures import seeded
+    g = golden("g7_gauss_affine.npz")
+    tr = RandomAffineWithInverse(degrees=15, scale=(0.8, 1.0), translate=(0.25, 0.25))
+    thetas = torch.cat([tr.create_affine_matrix(11.0, 0.87, (0.13, -0.21)), tr.create_affine_matrix(-14.0, 0.95, (-0.2, 0.05))])
+    img = seeded((2, 3, 20, 28), 77).abs()
+    w = tr(img, theta=thetas)
+    torch.testing.assert_close(w, torch.from_numpy(g["warp"]), rtol=2e-5, atol=2e-7)
+    torch.testing.assert_close(tr.inverse(w), torch.from_numpy(g["unwarp"]), rtol=2e-5, atol=2e-7)
+    torch.manual_seed(1234)
+    tr(img)
+    torch.testing.assert_close(tr.last_params["theta"], torch.from_numpy(g["theta_seed1234"]), rtol=0, atol=0)
+    from stablekeypoints_amd.ops import invert_affine
+    inv = torch.tensor(invert_affine(thetas[0].reshape(-1).tolist())).reshape(2, 3)
+    torch.testing.assert_close(inv, tr.invert(thetas[:1])[0], rtol=1e-5, atol=1e-6)
+
+
+def test_gaussian_and_scheduler_match_oracle(golden):
+    from stablekeypoints_amd.optimize_token import gaussian_circle, gaussian_circles
+    from stablekeypoints_amd.ldm.scheduler import DDIMScheduler
+    from oracle import ref_path as R
+    g = golden("g7_gauss_affine.npz")
+    pos = torch.tensor([[[0.3, 0.7], [0.5, 0.5], [0.02, 0.98]], [[0.9, 0.1], [0.25, 0.75], [0.6, 0.4]]])
+    torch.testing.assert_close(gaussian_circle(pos[0], 24, 2.0, "cpu"), torch.from_numpy(g["gaussian_circle"]))
+    torch.testing.assert_close(gaussian_circles(pos, 24, 3.0, "cpu"), torch.from_numpy(g["gaussian_circles"]))
+    s = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    s.set_timesteps(50)
+    assert torch.equal(s.timesteps, R.ddim_timesteps())
+    x, n = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    torch.testing.assert_close(s.add_noise(x, n, s.timesteps[-1]), R.add_noise(x, n, 0))
+
+
+def test_optimize_embedding_rejects_bad_batch():
+    from stablekeypoints_amd.optimize import optimize_embedding, default_args
+    from stablekeypoints_amd.ptp_utils import AttentionStore
+    with pytest.raises(ValueError, match="multiple of the data-parallel width"):
+        optimize_embedding(None, default_args(batch_size=0), {torch.device("cpu"): AttentionStore()}, 1)
+    a = default_args()
+    assert a.num_tokens == 500 and a.feature_upsample_res == 128 and a.top_k == 10 and a.lr == 5e-3
