@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-image-size", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--channels-last", action="store_true")
     return ap.parse_args()
 
 
@@ -63,18 +65,19 @@ def map_kernel_roofline(ops, B, T, R, iters, device):
     sides = [s for s, _ in dims]
     M, lse = ops._map_fwd(S, sides, B, H, T, R)
     dM = torch.randn_like(M)
-    dS = [torch.zeros_like(s_) for s_ in S]
+    dS = [torch.empty_like(s_) for s_ in S]
     from stablekeypoints_amd import _native as N
     sp, k1 = N.ptr_array([t.data_ptr() for t in S])
     dp, k2 = N.ptr_array([t.data_ptr() for t in dS])
     si, k3 = N.int_array(sides)
     st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(N.lib().skp_attn_map_bwd_workspace(si, 4, B, H, T, R) // 4, device=device)
 
     def run_fwd():
         N.check(N.lib().skp_attn_map_fwd_f32(sp, si, 4, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "fwd")
 
     def run_bwd():
-        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, 4, B, H, T, R, dM.data_ptr(), lse.data_ptr(), st), "bwd")
+        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, 4, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "bwd")
 
     out = {}
     for name, fn in (("fwd", run_fwd), ("bwd", run_bwd)):
@@ -137,6 +140,11 @@ def main():
         cpu_stats = cpu_baseline(ldm, a)
     # move the same instance to the GPU and install the fused hook (overrides the oracle's patch)
     ldm.to(dev)
+    if a.miopen_find:
+        torch.backends.cudnn.benchmark = True
+    if a.channels_last:
+        ldm.unet.to(memory_format=torch.channels_last)
+        ldm.vae.to(memory_format=torch.channels_last)
     from stablekeypoints_amd import ptp_utils
     controller = ptp_utils.AttentionStore()
     controllers = {dev: controller}

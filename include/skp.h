@@ -50,10 +50,10 @@ int skp_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int 
                     int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream);
 
 /* Low-resolution cross-attention logits of one hooked layer, log2 domain:
- *   S[b,h,t,p] = (scale*log2(e)) * sum_c k[bk,t,h*d+c] * q[b,p,h*d+c]
+ *   S[b,h,p,t] = (scale*log2(e)) * sum_c q[b,p,h*d+c] * k[bk,t,h*d+c]
  * q: [B, s*s, H*d] (= to_q(x), ptp_utils.py:483), k: [Bk, T, H*d] with Bk in {1,B}
  * (= to_k(context), :487; Bk==1 is the reference's context.repeat(B,1,1), ptp_utils.py:229),
- * S: [B, H, T, s*s]. */
+ * S: [B, H, s*s, NT] token-contiguous, NT = 16*ceil(T/16); columns t >= T are written as 0. */
 int skp_qk_logits_f32(const float* q, const float* k, float* S, int B, int Bk, int H, int T, int s2,
                       int d, float scale, void* stream);
 
@@ -65,16 +65,21 @@ int skp_qk_logits_f32(const float* q, const float* k, float* S, int B, int Bk, i
  * to_q is bias-free and bicubic resize is linear.
  * M:   [B, T, R, R]            (written)
  * lse: [B, L*H, R*R]           (written; log2-sum-exp per (layer, head, pixel), needed by _bwd)
- * Limits: 1 <= T <= 128, L <= SKP_MAX_LAYERS, s[l] <= 64.  */
+ * S[l]: [B, H, s[l]*s[l], NT] (layout of skp_qk_logits_f32).
+ * Limits: 1 <= T <= 128, L <= SKP_MAX_LAYERS, s[l] <= 64, R <= 4096.  */
 int skp_attn_map_fwd_f32(const float* const* S /*[host] L device ptrs*/, const int* s /*[host] L*/,
                          int L, int B, int H, int T, int R, float* M, float* lse, void* stream);
 
-/* Backward of skp_attn_map_fwd_f32: dS[l] (natural-log domain, i.e. d loss / d (scale*q.k),
- * shape of S[l]) += adjoint.  dS[l] must be ZERO-FILLED by the caller (accumulated with
- * fp32 atomics across tiles).  dM: [B,T,R,R]. */
+/* Bytes of scratch skp_attn_map_bwd_f32 needs (staging of the horizontally-reduced gradient between its
+ * two kernels); negative on bad arguments. */
+int64_t skp_attn_map_bwd_workspace(const int* s /*[host]*/, int L, int B, int H, int T, int R);
+
+/* Backward of skp_attn_map_fwd_f32: dS[l] (natural-log domain, i.e. d loss / d (scale*q.k), shape and
+ * layout of S[l]) is WRITTEN (every element, pad columns = 0).  Deterministic: no atomics.
+ * dM: [B,T,R,R]; workspace: skp_attn_map_bwd_workspace() bytes, contents irrelevant. */
 int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/,
                          const int* s /*[host]*/, int L, int B, int H, int T, int R,
-                         const float* dM, const float* lse, void* stream);
+                         const float* dM, const float* lse, float* workspace, void* stream);
 
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects

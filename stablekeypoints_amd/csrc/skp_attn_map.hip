@@ -5,99 +5,120 @@
 // per-head store of (B*h, R^2, T)) + optimize.py:27-79 (reshape/permute/stack/mean).
 // Algebra: to_q is bias-free and bicubic resize is linear, so
 //   scale * to_q(bicubic(x))[p] . k[t]  ==  bicubic( scale * to_q(x) . k[t] )[p]
-// i.e. the logits are up-sampled, not the activations: the 174.5 GF projection and the 11.3 GF
+// i.e. the LOGITS are up-sampled, not the activations: the 174.5 GF projection and the 11.3 GF
 // up-res QK^T of the reference collapse to a 0.2 GF low-res QK^T (skp_gemm.hip, fp32 MFMA) plus
-// 8 fma per (layer, head, token, pixel) here.  The kernel is VALU/LDS bound, not MFMA bound.
+// ~9 VALU ops per (layer, head, token, pixel) here.  The kernel is VALU/LDS-issue bound.
 //
-// Tiling: one workgroup = 256 consecutive pixels of the row-major R x R grid (lane = pixel, so
-// every M[t, y, x..x+63] store is one 256-B line) x ALL tokens (softmax is lane-local).
+// Data layout: logits S[l] are [B, H, s*s, NT] fp32, token-contiguous, NT = 16*ceil(T/16)
+// (columns t >= T are never read into results).  Pre-multiplied by scale*log2(e): exp2 = v_exp_f32.
+//
+// Tiling (row-aligned, any R): R <= 256: a workgroup owns TH = 256/R whole rows (lane = pixel,
+// x fastest => every M[t, y, x..x+63] store is a full 256-B line); R > 256: 256-pixel segments of a
+// row.  ALL tokens of a pixel live in one lane, so the softmax is lane-local (no cross-lane ops).
 // Per (layer, head):
-//   V phase  all threads: Vt[r][c][t] = sum_j wy[r][j] * S[t][cy[r][j]][c]   (rows r of the tile,
-//            every low-res column c) -> LDS, token-contiguous with stride NT+1 (conflict-free)
-//   H phase  lane: s_t = sum_i wx[i] * Vt[r(lane)][cx[i]][t]  (4 LDS reads, immediate offsets)
-//            m = max_t s_t; e_t = exp2(s_t - m); acc_t += e_t / sum_t e_t
-// The logits arrive pre-multiplied by scale*log2(e), so exp2 is the bare v_exp_f32.
+//   V phase  Vt[r][c][t] = sum_j wy[r][j] * S[cy[r][j]][c][t]   float4 over t, coalesced -> LDS
+//            (token stride NT+1: conflict-free for the per-lane column gathers below)
+//   H phase  s_t = sum_i wx[i] * Vt[r(lane)][cx[i]][t]          4 LDS reads with immediate offsets
+//            FWD: m = max s; e = exp2(s-m); acc_t += e / sum e;  lse = m + log2(sum e)
+//            BWD: p = exp2(s-lse); dS_t = p (g_t - sum p g);  horizontal adjoint by an LDS
+//                 transpose + gather (deterministic, no atomics) -> dV[y][seg][c][t] in HBM
+//   second backward kernel: vertical adjoint dS[cy][c][t] = sum_y Wy(y,cy) sum_seg dV[y][seg][c][t]
 #include "skp_common.h"
 
 struct MapArgs {
     const float* S[SKP_MAX_LAYERS];
     float* dS[SKP_MAX_LAYERS];
     int s[SKP_MAX_LAYERS];
+    long dv_off[SKP_MAX_LAYERS];   // float offset of layer l inside the dV workspace (per batch row 0)
+    long dv_per_b;                 // floats of dV per batch row
     int L, B, H, T, R;
-    int th_max;          // max tile rows
-    int vt_floats;       // floats of one Vt buffer
+    int TH, TW, segs, smax;        // tile rows, tile width, segments per row, max layer side
+    int vt_floats;                 // floats of the Vt buffer
     float inv_lh;
 };
 
-// Row/column tap tables live after the Vt buffer(s): cy[th_max*4] (int) then wy[th_max*4] (float).
-template <int NT, bool BWD>
-__global__ __launch_bounds__(256) void skp_attn_map_kernel(MapArgs a, float* __restrict__ M,
-                                                           float* __restrict__ lse_out,
-                                                           const float* __restrict__ dM,
-                                                           const float* __restrict__ lse_in) {
+// lane -> pixel of the row-aligned tile
+struct Tile { int y0, seg, ry, x, th_eff; bool valid; };
+
+__device__ __forceinline__ Tile skp_tile(const MapArgs& a, int blk, int tid) {
+    Tile t;
+    if (a.R <= 256) {
+        t.y0 = blk * a.TH; t.seg = 0;
+        t.ry = tid / a.R; t.x = tid - t.ry * a.R;
+        t.th_eff = (a.R - t.y0 < a.TH) ? a.R - t.y0 : a.TH;
+        t.valid = t.ry < t.th_eff;
+    } else {
+        t.y0 = blk / a.segs; t.seg = blk - t.y0 * a.segs;
+        t.ry = 0; t.x = t.seg * 256 + tid; t.th_eff = 1;
+        t.valid = t.x < a.R;
+    }
+    if (!t.valid) { t.ry = 0; t.x = (a.R <= 256) ? 0 : a.R - 1; }
+    return t;
+}
+
+// V phase shared by forward and backward.  tab_cy/tab_wy hold the row taps of the tile's rows.
+template <int NT>
+__device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float* __restrict__ Vt,
+                                            const int* __restrict__ tab_cy, const float* __restrict__ tab_wy,
+                                            int s, int rc, int tid) {
+    constexpr int TS = NT + 1, Q = NT / 4;
+    const float inv_s = 1.0f / (float)s;
+    const int items = rc * Q;
+#pragma unroll 2
+    for (int it = tid; it < items; it += 256) {
+        const int r = it / Q, q4 = it - r * Q;               // r = row*s + c
+        const int row = (int)(((float)r + 0.5f) * inv_s);
+        const int c = r - row * s;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * NT + q4 * 4);
+            acc += tab_wy[row * 4 + j] * v;
+        }
+        float* o = Vt + r * TS + q4 * 4;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float* __restrict__ M,
+                                                               float* __restrict__ lse_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 1;                                 // token stride (odd => conflict-free)
+    constexpr int TS = NT + 1;
     const int tid = threadIdx.x, b = blockIdx.y;
     const int R = a.R, T = a.T, H = a.H, RR = R * R;
-    const int p0 = blockIdx.x * 256;
-    const int p = p0 + tid;
-    const bool valid = p < RR;
-    const int pc = valid ? p : RR - 1;
-    const int y = pc / R, x = pc - y * R;
-    const int y0 = p0 / R;
-    const int plast = (p0 + 255 < RR - 1) ? p0 + 255 : RR - 1;
-    const int TH = plast / R - y0 + 1;
-    const int ry = y - y0;
-
+    const Tile tl = skp_tile(a, blockIdx.x, tid);
+    const int p = (tl.y0 + tl.ry) * R + tl.x;
     float* Vt = smem;
-    float* dVt = smem + a.vt_floats;                           // BWD only
-    int* tab_cy = (int*)(smem + (BWD ? 2 : 1) * a.vt_floats);
-    float* tab_wy = (float*)(tab_cy + a.th_max * 4);
+    int* tab_cy = (int*)(smem + a.vt_floats);
+    float* tab_wy = (float*)(tab_cy + a.TH * 4);
 
-    float acc[NT];                                             // FWD: map accumulator; BWD: g = dM/(L*H)
+    float acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (BWD) acc[t] = (valid && t < T) ? dM[((size_t)b * T + t) * RR + p] * a.inv_lh : 0.f;
-        else acc[t] = 0.f;
-    }
+    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
 
     int lh = 0;
     for (int l = 0; l < a.L; ++l) {
         const int s = a.s[l];
         const float ratio = (float)s / (float)R;
         int cx[4]; float wx[4];
-        skp_cubic_taps(x, ratio, s, cx, wx);
+        skp_cubic_taps(tl.x, ratio, s, cx, wx);
         int base[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) base[i] = (ry * s + cx[i]) * TS;
-        __syncthreads();                                       // previous layer finished with the tables
-        if (tid < TH) {
+        for (int i = 0; i < 4; ++i) base[i] = (tl.ry * s + cx[i]) * TS;
+        __syncthreads();                                       // previous layer done with the tables
+        if (tid < tl.th_eff) {
             int cy[4]; float wy[4];
-            skp_cubic_taps(y0 + tid, ratio, s, cy, wy);
+            skp_cubic_taps(tl.y0 + tid, ratio, s, cy, wy);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
         }
-        const int rc = TH * s;
-        const int nvt = rc * T;
-        const float inv_rc = 1.0f / (float)rc, inv_s = 1.0f / (float)s;
+        const int rc = tl.th_eff * s;
         for (int h = 0; h < H; ++h, ++lh) {
-            const float* Sg = a.S[l] + ((size_t)(b * H + h) * T) * s * s;
+            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * NT;
             __syncthreads();                                   // tables ready / previous H phase done
-            // ---- V phase -------------------------------------------------------------------
-            for (int idx = tid; idx < nvt; idx += 256) {
-                const int t = (int)(((float)idx + 0.5f) * inv_rc);
-                const int r = idx - t * rc;                    // r = row*s + c
-                const int row = (int)(((float)r + 0.5f) * inv_s);
-                const int c = r - row * s;
-                const float* St = Sg + (size_t)t * s * s + c;
-                float v = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v = fmaf(tab_wy[row * 4 + j], St[tab_cy[row * 4 + j] * s], v);
-                Vt[r * TS + t] = v;
-                if (BWD) dVt[r * TS + t] = 0.f;
-            }
+            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid);
             __syncthreads();
-            // ---- H phase + softmax over tokens (lane-local) ---------------------------------
             float sv[NT];
             float m = -INFINITY;
 #pragma unroll
@@ -109,86 +130,194 @@ __global__ __launch_bounds__(256) void skp_attn_map_kernel(MapArgs a, float* __r
                 sv[t] = (t < T) ? v : -INFINITY;
                 m = fmaxf(m, sv[t]);
             }
-            if (!BWD) {
-                float sum = 0.f;
+            float sum = 0.f;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { sv[t] = __builtin_amdgcn_exp2f(sv[t] - m); sum += sv[t]; }
-                const float inv = 1.0f / sum;
+            for (int t = 0; t < NT; ++t) { sv[t] = __builtin_amdgcn_exp2f(sv[t] - m); sum += sv[t]; }
+            const float inv = 1.0f / sum;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = fmaf(sv[t], inv, acc[t]);
-                if (valid) lse_out[((size_t)b * a.L * H + lh) * RR + p] = m + __builtin_amdgcn_logf(sum);
-            } else {
-                const float lse = lse_in[((size_t)b * a.L * H + lh) * RR + pc];
-                float dot = 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { sv[t] = __builtin_amdgcn_exp2f(sv[t] - lse); dot = fmaf(sv[t], acc[t], dot); }
-                // adjoint of the H phase: scatter w_i * dS_t into dVt (LDS fp32 atomics)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float ds = valid ? sv[t] * (acc[t] - dot) : 0.f;
-                    if (t < T) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) atomicAdd(&dVt[base[i] + t], wx[i] * ds);
-                    }
-                }
-                __syncthreads();
-                // adjoint of the V phase: dS[t][cy][c] += wy * dVt  (global fp32 atomics; tiles overlap)
-                float* dSg = a.dS[l] + ((size_t)(b * H + h) * T) * s * s;
-                for (int idx = tid; idx < nvt; idx += 256) {
-                    const int t = (int)(((float)idx + 0.5f) * inv_rc);
-                    const int r = idx - t * rc;
-                    const int row = (int)(((float)r + 0.5f) * inv_s);
-                    const int c = r - row * s;
-                    const float v = dVt[r * TS + t];
-                    float* dSt = dSg + (size_t)t * s * s + c;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) atomicAdd(&dSt[tab_cy[row * 4 + j] * s], tab_wy[row * 4 + j] * v);
-                }
-            }
+            for (int t = 0; t < NT; ++t) acc[t] = fmaf(sv[t], inv, acc[t]);
+            if (tl.valid) lse_out[((size_t)b * a.L * H + lh) * RR + p] = m + __builtin_amdgcn_logf(sum);
         }
     }
-    if (!BWD && valid) {
+    if (tl.valid) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (t < T) M[((size_t)b * T + t) * RR + p] = acc[t] * a.inv_lh;
     }
 }
 
-template <bool BWD>
-static int launch_map(MapArgs& a, float* M, float* lse_out, const float* dM, const float* lse_in, hipStream_t st) {
-    int smax = 0;
-    for (int l = 0; l < a.L; ++l) smax = a.s[l] > smax ? a.s[l] : smax;
-    const int R = a.R;
-    int th = (256 + R - 1) / R + 1;
-    if (th > R) th = R;
-    a.th_max = th;
-    const int nt = ((a.T + 15) / 16) * 16;
-    a.vt_floats = th * smax * (nt + 1);
-    const size_t lds = ((size_t)(BWD ? 2 : 1) * a.vt_floats + 8 * (size_t)th) * sizeof(float);
-    if (lds > 160 * 1024) return SKP_E_LDS;
-    dim3 grid((R * R + 255) / 256, a.B), block(256);
-#define SKP_MAP_CASE(NTV)                                                                              \
-    case NTV:                                                                                          \
-        if (lds > 64 * 1024) {                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_kernel<NTV, BWD>,            \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            if (e != hipSuccess) return (int)e;                                                        \
-        }                                                                                              \
-        hipLaunchKernelGGL((skp_attn_map_kernel<NTV, BWD>), grid, block, lds, st, a, M, lse_out, dM, lse_in); \
-        break;
-    switch (nt) {
-        SKP_MAP_CASE(16) SKP_MAP_CASE(32) SKP_MAP_CASE(48) SKP_MAP_CASE(64)
-        SKP_MAP_CASE(80) SKP_MAP_CASE(96) SKP_MAP_CASE(112) SKP_MAP_CASE(128)
-        default: return SKP_E_RANGE;
+// Backward, kernel A.  LDS: Vt | dSx[256][TC+1] | Wt[smax][TW] | xlo[smax] xhi[smax] | row tables.
+template <int NT>
+__global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const float* __restrict__ dM,
+                                                               const float* __restrict__ lse_in,
+                                                               float* __restrict__ dV) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TS = NT + 1;
+    constexpr int NCH = (NT > 48) ? 2 : 1;                     // the transpose buffer holds NT/NCH tokens at a time
+    constexpr int TC = NT / NCH, TSC = TC + 1, TQ = TC / 4;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int R = a.R, T = a.T, H = a.H, RR = R * R;
+    const Tile tl = skp_tile(a, blockIdx.x, tid);
+    const int p = (tl.y0 + tl.ry) * R + tl.x;
+    const int xl = tl.x - tl.seg * 256;                        // column inside the tile
+    float* Vt = smem;
+    float* dSx = smem + a.vt_floats;
+    float* Wt = dSx + 256 * TSC;
+    int* xlo = (int*)(Wt + a.smax * a.TW);
+    int* xhi = xlo + a.smax;
+    int* tab_cy = xhi + a.smax;
+    float* tab_wy = (float*)(tab_cy + a.TH * 4);
+
+    float g[NT];                                               // dM / (L*H), lane-local
+#pragma unroll
+    for (int t = 0; t < NT; ++t) g[t] = (tl.valid && t < T) ? dM[((size_t)b * T + t) * RR + p] * a.inv_lh : 0.f;
+
+    int lh = 0;
+    for (int l = 0; l < a.L; ++l) {
+        const int s = a.s[l];
+        const float ratio = (float)s / (float)R;
+        int cx[4]; float wx[4];
+        skp_cubic_taps(tl.x, ratio, s, cx, wx);
+        int base[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base[i] = (tl.ry * s + cx[i]) * TS;
+        __syncthreads();                                       // previous layer done with tables / Wt
+        if (tid < tl.th_eff) {
+            int cy[4]; float wy[4];
+            skp_cubic_taps(tl.y0 + tid, ratio, s, cy, wy);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
+        }
+        for (int i = tid; i < s * a.TW; i += 256) Wt[i] = 0.f;
+        if (tid < s) { xlo[tid] = 0x7fffffff; xhi[tid] = -1; }
+        __syncthreads();
+        if (tl.valid && tl.ry == 0) {                          // transpose of the horizontal taps: Wt[c][x]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                      // same-lane adds are program-ordered => deterministic
+                atomicAdd(&Wt[cx[i] * a.TW + xl], wx[i]);
+                atomicMin(&xlo[cx[i]], xl);
+                atomicMax(&xhi[cx[i]], xl);
+            }
+        }
+        const int rc = tl.th_eff * s;
+        const float inv_s = 1.0f / (float)s;
+        for (int h = 0; h < H; ++h, ++lh) {
+            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * NT;
+            __syncthreads();                                   // tables/Wt ready; previous gather done
+            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid);
+            __syncthreads();
+            const float lse = tl.valid ? lse_in[((size_t)b * a.L * H + lh) * RR + p] : 0.f;
+            float sv[NT];
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float v = wx[0] * Vt[base[0] + t];
+                v = fmaf(wx[1], Vt[base[1] + t], v);
+                v = fmaf(wx[2], Vt[base[2] + t], v);
+                v = fmaf(wx[3], Vt[base[3] + t], v);
+                sv[t] = (t < T) ? __builtin_amdgcn_exp2f(v - lse) : 0.f;
+                dot = fmaf(sv[t], g[t], dot);
+            }
+            float* dVg = dV + (size_t)b * a.dv_per_b + a.dv_off[l] +
+                         ((size_t)h * R + tl.y0) * a.segs * s * NT;          // [h][y][seg][c][t]
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch) __syncthreads();                       // previous chunk's gather done
+#pragma unroll
+                for (int tt = 0; tt < TC; ++tt) {
+                    const int t = ch * TC + tt;
+                    dSx[tid * TSC + tt] = tl.valid ? sv[t] * (g[t] - dot) : 0.f;
+                }
+                __syncthreads();
+                // gather: dV[row][c][t] = sum_x Wt[c][x] * dS[row][x][t]; each item = (row, c, 4 strided tokens)
+                const int items = rc * TQ;
+                for (int it = tid; it < items; it += 256) {
+                    const int r = it / TQ, tq = it - r * TQ;
+                    const int row = (int)(((float)r + 0.5f) * inv_s);
+                    const int c = r - row * s;
+                    const int lo = xlo[c], hi = xhi[c];
+                    const float* w = Wt + c * a.TW;
+                    const float* d = dSx + (size_t)(row * a.TW) * TSC + tq;
+                    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                    for (int xx = lo; xx <= hi; ++xx) {
+                        const float ww = w[xx];
+                        const float* dd = d + xx * TSC;
+                        o0 = fmaf(ww, dd[0], o0); o1 = fmaf(ww, dd[TQ], o1);
+                        o2 = fmaf(ww, dd[2 * TQ], o2); o3 = fmaf(ww, dd[3 * TQ], o3);
+                    }
+                    float* out = dVg + ((size_t)(row * a.segs + tl.seg) * s + c) * NT + ch * TC + tq;
+                    out[0] = o0; out[TQ] = o1; out[2 * TQ] = o2; out[3 * TQ] = o3;
+                }
+            }
+        }
     }
-#undef SKP_MAP_CASE
-    return skp_launch_status();
 }
 
+// Backward, kernel B: vertical adjoint.  grid = (sum_l H*s_l, B); one workgroup per (layer, head, low-res row).
+struct VAdjArgs {
+    float* dS[SKP_MAX_LAYERS];
+    int s[SKP_MAX_LAYERS];
+    long dv_off[SKP_MAX_LAYERS];
+    int blk_off[SKP_MAX_LAYERS + 1];   // first block of layer l
+    long dv_per_b;
+    int L, H, R, segs, NT;
+};
+
+__global__ __launch_bounds__(256) void skp_attn_map_vadj_kernel(VAdjArgs a, const float* __restrict__ dV) {
+    const int tid = threadIdx.x, b = blockIdx.y;
+    int l = 0;
+    while (l + 1 < a.L && (int)blockIdx.x >= a.blk_off[l + 1]) ++l;
+    const int s = a.s[l], NT = a.NT, Q = NT / 4, R = a.R;
+    const int rel = blockIdx.x - a.blk_off[l];
+    const int h = rel / s, cy = rel - h * s;
+    const float ratio = (float)s / (float)R;
+    // rows y whose taps can touch cy: src(y) in (cy-2.5, cy+2.5) (+ everything beyond the clamped borders)
+    int ylo = (int)floorf(((float)cy - 2.0f) / ratio) - 2, yhi = (int)ceilf(((float)cy + 3.0f) / ratio) + 2;
+    if (cy == 0) ylo = 0;
+    if (cy == s - 1) yhi = R - 1;
+    ylo = ylo < 0 ? 0 : ylo; yhi = yhi > R - 1 ? R - 1 : yhi;
+    const float* dVg = dV + (size_t)b * a.dv_per_b + a.dv_off[l] + (size_t)h * R * a.segs * s * NT;
+    float* out = a.dS[l] + (((size_t)b * a.H + h) * s * s + (size_t)cy * s) * NT;
+    // each thread owns up to MAXI float4 slots (it = c*Q + q4: contiguous floats of one dV row)
+    constexpr int MAXI = 8;                                    // s <= 64, NT <= 128 => s*Q <= 2048 = 8*256
+    const int nit = s * Q;
+    f32x4 acc[MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int y = ylo; y <= yhi; ++y) {
+        int ty[4]; float wy[4];
+        skp_cubic_taps(y, ratio, s, ty, wy);                   // uniform across the workgroup
+        float w = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w += (ty[j] == cy) ? wy[j] : 0.f;
+        if (w == 0.f) continue;
+        for (int sg = 0; sg < a.segs; ++sg) {
+            const float* row = dVg + ((size_t)(y * a.segs + sg) * s) * NT;
+#pragma unroll
+            for (int u = 0; u < MAXI; ++u) {
+                const int it = tid + u * 256;
+                if (it < nit) acc[u] += w * *(const f32x4*)(row + it * 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        const int it = tid + u * 256;
+        if (it < nit) *(f32x4*)(out + it * 4) = acc[u];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const int* s, int L, int B, int H,
                      int T, int R) {
     if (!S || !s || L <= 0 || B <= 0 || H <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
-    if (L > SKP_MAX_LAYERS || T > 128 || B > 65535) return SKP_E_RANGE;
+    if (L > SKP_MAX_LAYERS || T > 128 || B > 65535 || R > 4096) return SKP_E_RANGE;
+    const int nt = ((T + 15) / 16) * 16;
+    int smax = 0;
+    long off = 0;
+    a.R = R;
+    if (R <= 256) { a.TH = 256 / R; a.TW = R; a.segs = 1; }
+    else { a.TH = 1; a.TW = 256; a.segs = (R + 255) / 256; }
     for (int l = 0; l < L; ++l) {
         if (!S[l] || s[l] <= 0) return SKP_E_BADARG;
         if (s[l] > 64) return SKP_E_RANGE;
@@ -196,11 +325,27 @@ static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const 
         a.dS[l] = dS ? dS[l] : nullptr;
         if (dS && !dS[l]) return SKP_E_BADARG;
         a.s[l] = s[l];
+        a.dv_off[l] = off;
+        off += (long)H * R * a.segs * s[l] * nt;
+        smax = s[l] > smax ? s[l] : smax;
     }
-    a.L = L; a.B = B; a.H = H; a.T = T; a.R = R;
+    a.dv_per_b = off;
+    a.L = L; a.B = B; a.H = H; a.T = T; a.smax = smax;
+    a.vt_floats = a.TH * smax * (nt + 1);
+    a.vt_floats = (a.vt_floats + 3) & ~3;
     a.inv_lh = 1.0f / (float)(L * H);
     return 0;
 }
+
+static int n_tiles(const MapArgs& a) { return a.R <= 256 ? (a.R + a.TH - 1) / a.TH : a.R * a.segs; }
+
+#define SKP_NT_SWITCH(nt, MACRO)                                                                        \
+    switch (nt) {                                                                                       \
+        case 16: MACRO(16) break; case 32: MACRO(32) break; case 48: MACRO(48) break;                    \
+        case 64: MACRO(64) break; case 80: MACRO(80) break; case 96: MACRO(96) break;                    \
+        case 112: MACRO(112) break; case 128: MACRO(128) break;                                         \
+        default: return SKP_E_RANGE;                                                                    \
+    }
 
 extern "C" int skp_attn_map_fwd_f32(const float* const* S, const int* s, int L, int B, int H, int T, int R,
                                     float* M, float* lse, void* stream) {
@@ -208,15 +353,66 @@ extern "C" int skp_attn_map_fwd_f32(const float* const* S, const int* s, int L, 
     int rc = fill_args(a, S, nullptr, s, L, B, H, T, R);
     if (rc) return rc;
     if (!M || !lse) return SKP_E_BADARG;
-    return launch_map<false>(a, M, lse, nullptr, nullptr, (hipStream_t)stream);
+    const int nt = ((T + 15) / 16) * 16;
+    const size_t lds = ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
+    if (lds > 160 * 1024) return SKP_E_LDS;
+    dim3 grid(n_tiles(a), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SKP_FWD(NTV)                                                                                     \
+    if (lds > 64 * 1024) {                                                                               \
+        hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_fwd_kernel<NTV>,                    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        if (e != hipSuccess) return (int)e;                                                              \
+    }                                                                                                    \
+    hipLaunchKernelGGL((skp_attn_map_fwd_kernel<NTV>), grid, block, lds, st, a, M, lse);
+    SKP_NT_SWITCH(nt, SKP_FWD)
+#undef SKP_FWD
+    return skp_launch_status();
+}
+
+extern "C" int64_t skp_attn_map_bwd_workspace(const int* s, int L, int B, int H, int T, int R) {
+    if (!s || L <= 0 || L > SKP_MAX_LAYERS || B <= 0 || H <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
+    const int nt = ((T + 15) / 16) * 16;
+    const int segs = R <= 256 ? 1 : (R + 255) / 256;
+    int64_t fl = 0;
+    for (int l = 0; l < L; ++l) fl += (int64_t)H * R * segs * s[l] * nt;
+    return fl * B * (int64_t)sizeof(float);
 }
 
 extern "C" int skp_attn_map_bwd_f32(const float* const* S, float* const* dS, const int* s, int L, int B, int H,
-                                    int T, int R, const float* dM, const float* lse, void* stream) {
+                                    int T, int R, const float* dM, const float* lse, float* workspace,
+                                    void* stream) {
     MapArgs a{};
     if (!dS) return SKP_E_BADARG;
     int rc = fill_args(a, S, dS, s, L, B, H, T, R);
     if (rc) return rc;
-    if (!dM || !lse) return SKP_E_BADARG;
-    return launch_map<true>(a, nullptr, nullptr, dM, lse, (hipStream_t)stream);
+    if (!dM || !lse || !workspace) return SKP_E_BADARG;
+    const int nt = ((T + 15) / 16) * 16;
+    const int tc = nt > 48 ? nt / 2 : nt;
+    const size_t lds = ((size_t)a.vt_floats + 256 * (size_t)(tc + 1) + (size_t)a.smax * a.TW + 2 * (size_t)a.smax +
+                        8 * (size_t)a.TH) * sizeof(float);
+    if (lds > 160 * 1024) return SKP_E_LDS;
+    dim3 grid(n_tiles(a), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SKP_BWD(NTV)                                                                                     \
+    if (lds > 64 * 1024) {                                                                               \
+        hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_bwd_kernel<NTV>,                    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        if (e != hipSuccess) return (int)e;                                                              \
+    }                                                                                                    \
+    hipLaunchKernelGGL((skp_attn_map_bwd_kernel<NTV>), grid, block, lds, st, a, dM, lse, workspace);
+    SKP_NT_SWITCH(nt, SKP_BWD)
+#undef SKP_BWD
+    rc = skp_launch_status();
+    if (rc) return rc;
+    VAdjArgs v{};
+    int nblk = 0;
+    for (int l = 0; l < L; ++l) {
+        v.dS[l] = a.dS[l]; v.s[l] = a.s[l]; v.dv_off[l] = a.dv_off[l]; v.blk_off[l] = nblk;
+        nblk += H * a.s[l];
+    }
+    v.blk_off[L] = nblk;
+    v.dv_per_b = a.dv_per_b; v.L = L; v.H = H; v.R = R; v.segs = a.segs; v.NT = nt;
+    hipLaunchKernelGGL(skp_attn_map_vadj_kernel, dim3(nblk, B), dim3(256), 0, st, v, (const float*)workspace);
+    return skp_launch_status();
 }

@@ -8,6 +8,7 @@
 struct GemmArgs {
     const float* A; const float* B; float* C;
     int M, N, K, Z1;
+    int Nload;                 // rows of B that exist (n >= Nload reads as 0; still stored when n < N)
     int64_t sa0, sa1, sam, sak;
     int64_t sb0, sb1, sbn, sbk;
     int64_t sc0, sc1, scm;
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     const int m0 = (blockIdx.y * 2 + (wave >> 1)) * 32;
     if (m0 >= g.M || n0 >= g.N) return;                       // wave-uniform
     const int z0 = blockIdx.z / g.Z1, z1 = blockIdx.z - z0 * g.Z1;
-    const bool mv = (m0 + i) < g.M, nv = (n0 + i) < g.N;
+    const bool mv = (m0 + i) < g.M, nv = (n0 + i) < g.Nload, ns = (n0 + i) < g.N;
     const float* Ap = g.A + z0 * g.sa0 + z1 * g.sa1 + (int64_t)(mv ? m0 + i : 0) * g.sam + hi * g.sak;
     const float* Bp = g.B + z0 * g.sb0 + z1 * g.sb1 + (int64_t)(nv ? n0 + i : 0) * g.sbn + hi * g.sbk;
     f32x16 acc = {0};
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     }
     // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
     float* Cp = g.C + z0 * g.sc0 + z1 * g.sc1;
-    if (nv) {
+    if (ns) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -55,16 +56,23 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+static int gemm_launch(const float* A, const float* B, float* C, int M, int N, int Nload, int K, int Z0, int Z1,
+                       int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
+                       int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
+                       int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || Z0 <= 0 || Z1 <= 0) return SKP_E_BADARG;
+    if ((int64_t)Z0 * Z1 > 65535) return SKP_E_RANGE;
+    GemmArgs g{A, B, C, M, N, K, Z1, Nload, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
+    dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1);
+    hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return skp_launch_status();
+}
+
 extern "C" int skp_gemm_nt_f32(const float* A, const float* B, float* C, int M, int N, int K, int Z0, int Z1,
                                int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
                                int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
                                int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || Z0 <= 0 || Z1 <= 0) return SKP_E_BADARG;
-    if ((int64_t)Z0 * Z1 > 65535) return SKP_E_RANGE;
-    GemmArgs g{A, B, C, M, N, K, Z1, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
-    dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1);
-    hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
-    return skp_launch_status();
+    return gemm_launch(A, B, C, M, N, N, K, Z0, Z1, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha, stream);
 }
 
 extern "C" int skp_qk_logits_f32(const float* q, const float* k, float* S, int B, int Bk, int H, int T, int s2,
@@ -72,9 +80,10 @@ extern "C" int skp_qk_logits_f32(const float* q, const float* k, float* S, int B
     if (!q || !k || !S || B <= 0 || H <= 0 || T <= 0 || s2 <= 0 || d <= 0) return SKP_E_BADARG;
     if (Bk != 1 && Bk != B) return SKP_E_BADARG;
     const int64_t C = (int64_t)H * d;
-    // S[b,h][t,p] = alpha * sum_c k[b,t,h*d+c] * q[b,p,h*d+c]
-    return skp_gemm_nt_f32(k, q, S, T, s2, d, B, H,
-                           Bk == 1 ? 0 : (int64_t)T * C, d, C, 1,
-                           (int64_t)s2 * C, d, C, 1,
-                           (int64_t)H * T * s2, (int64_t)T * s2, s2, scale * SKP_LOG2E, stream);
+    const int NT = ((T + 15) / 16) * 16;
+    // S[b,h][p,t] = alpha * sum_c q[b,p,h*d+c] * k[bk,t,h*d+c]; token-contiguous rows of NT floats, pad columns = 0
+    return gemm_launch(q, k, S, s2, NT, T, d, B, H,
+                       (int64_t)s2 * C, d, C, 1,
+                       Bk == 1 ? 0 : (int64_t)T * C, d, C, 1,
+                       (int64_t)H * s2 * NT, (int64_t)s2 * NT, NT, scale * SKP_LOG2E, stream);
 }

@@ -30,13 +30,14 @@ def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
 # low-res logits (fp32 MFMA)                                            ptp_utils.py:483-493
 # ---------------------------------------------------------------------------------------------
 def qk_logits(q: torch.Tensor, k: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """S[b,h,t,p] = scale*log2(e) * <k[bk,t,h,:], q[b,p,h,:]>;  q [B,s2,C], k [Bk,T,C] -> [B,H,T,s2]."""
+    """S[b,h,p,t] = scale*log2(e) * <q[b,p,h,:], k[bk,t,h,:]>;  q [B,s2,C], k [Bk,T,C] -> [B,H,s2,NT]
+    (token-contiguous, NT = 16*ceil(T/16), pad columns zero)."""
     q, k = _dev(q, "q"), _dev(k, "k")
     B, s2, C = q.shape
     Bk, T, Ck = k.shape
     if Ck != C or C % heads:
         raise RuntimeError("qk_logits: channel mismatch")
-    S = torch.empty(B, heads, T, s2, device=q.device, dtype=torch.float32)
+    S = torch.empty(B, heads, s2, (T + 15) // 16 * 16, device=q.device, dtype=torch.float32)
     N.check(N.lib().skp_qk_logits_f32(q.data_ptr(), k.data_ptr(), S.data_ptr(), B, Bk, heads, T, s2,
                                       C // heads, float(scale), _stream()), "skp_qk_logits_f32")
     return S
@@ -89,28 +90,33 @@ class AttnMapFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         lse, qs, ks, S = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:]
         dM = _dev(dM, "dM")
-        dS = [torch.zeros_like(s_) for s_ in S]
+        dS = [torch.empty_like(s_) for s_ in S]
         sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
         dp, _k2 = N.ptr_array([t.data_ptr() for t in dS])
         si, _k3 = N.int_array(sides)
-        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, L, B, H, T, R, dM.data_ptr(), lse.data_ptr(), _stream()),
-                "skp_attn_map_bwd_f32")
+        nbytes = N.lib().skp_attn_map_bwd_workspace(si, L, B, H, T, R)
+        if nbytes < 0:
+            N.check(int(nbytes), "skp_attn_map_bwd_workspace")
+        ws = torch.empty(nbytes // 4, device=dM.device, dtype=torch.float32)
+        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, L, B, H, T, R, dM.data_ptr(), lse.data_ptr(),
+                                             ws.data_ptr(), _stream()), "skp_attn_map_bwd_f32")
         grads: List[torch.Tensor] = []
         for l in range(L):
             q, k, ds, sc = qs[l], ks[l], dS[l], scales[l]
             s2, C = q.shape[1], q.shape[2]
             d = C // H
             Bk = k.shape[0]
+            NT = ds.shape[-1]
             dq = dk = None
             if ctx.needs_input_grad[3 + 2 * l]:
-                dq = torch.empty_like(q)       # dq[b,p,h*d+c] = sc * sum_t dS[b,h,t,p] k[bk,t,h*d+c]
+                dq = torch.empty_like(q)       # dq[b,p,h*d+c] = sc * sum_t dS[b,h,p,t] k[bk,t,h*d+c]
                 _gemm_nt(ds, k, dq, s2, d, T, B, H,
-                         (H * T * s2, T * s2, 1, s2), (0 if Bk == 1 else T * C, d, 1, C),
+                         (H * s2 * NT, s2 * NT, NT, 1), (0 if Bk == 1 else T * C, d, 1, C),
                          (s2 * C, d, C), sc)
             if ctx.needs_input_grad[4 + 2 * l]:
                 dkb = torch.empty(B, T, C, device=q.device, dtype=torch.float32)
-                _gemm_nt(ds, q, dkb, T, d, s2, B, H,    # dk[b,t,h*d+c] = sc * sum_p dS[b,h,t,p] q[b,p,h*d+c]
-                         (H * T * s2, T * s2, s2, 1), (s2 * C, d, 1, C), (T * C, d, C), sc)
+                _gemm_nt(ds, q, dkb, T, d, s2, B, H,    # dk[b,t,h*d+c] = sc * sum_p dS[b,h,p,t] q[b,p,h*d+c]
+                         (H * s2 * NT, s2 * NT, 1, NT), (s2 * C, d, 1, C), (T * C, d, C), sc)
                 dk = dkb.sum(dim=0, keepdim=True) if (Bk == 1 and B > 1) else dkb
             grads += [dq, dk]
         return (None, None, None, *grads)

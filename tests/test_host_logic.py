@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_c_abi_exports_every_declared_symbol():
     from stablekeypoints_amd import _native as N
     hdr = open(os.path.join(ROOT, "include", "skp.h")).read()
-    declared = sorted(set(re.findall(r"^int\s+(skp_\w+)\s*\(", hdr, flags=re.M)))
+    declared = sorted(set(re.findall(r"^int(?:64_t)?\s+(skp_\w+)\s*\(", hdr, flags=re.M)))
     assert len(declared) >= 9
     lib = N.lib()                                   # dlopen works without a GPU
     for name in declared:
