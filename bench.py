@@ -149,6 +149,7 @@ def main():
     controller = ptp_utils.AttentionStore()
     controllers = {dev: controller}
     ptp_utils.register_attention_control(ldm.unet, controller, feature_upsample_res=a.res)
+    ptp_utils.accelerate_cross_attention(ldm.unet)
     t_build = time.time() - t_build
 
     per_rank = a.images_per_rank

@@ -14,6 +14,7 @@
  *   skp_qk_logits_f32 / skp_gemm_nt_f32     ptp_utils.py:483-493,531-534 (q.k^T contractions)
  *   skp_attn_map_fwd_f32 / _bwd_f32         ptp_utils.py:513-538 + optimize.py:27-79
  *                                           (bicubic up-res softmax map, per-head store, layer/head mean)
+ *   skp_cross_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (ordinary softmax(QK^T)V, cross layers)
  *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
  *   skp_select_tokens                       ptp_utils.py:110-112,115-159
  *   skp_losses_fwd_f32                      optimize.py:157-206, optimize_token.py:203-241,
@@ -80,6 +81,22 @@ int64_t skp_attn_map_bwd_workspace(const int* s /*[host]*/, int L, int B, int H,
 int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/,
                          const int* s /*[host]*/, int L, int B, int H, int T, int R,
                          const float* dM, const float* lse, float* workspace, void* stream);
+
+/* Ordinary cross-attention core (ptp_utils.py:493-506,540) for a short key axis, fp32 MFMA, K/V staged in
+ * LDS, softmax over the tokens in registers:
+ *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]
+ * q, out: [B,N,H*d]; k, v: [Bk,T,H*d] with Bk in {1,B}; lse: [B,H,N] natural-log sum-exp (for _bwd).
+ * Limits: T <= 128, d in {8,16,40,80,160}. */
+int skp_cross_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
+                           int B, int Bk, int H, int N, int T, int d, float scale, void* stream);
+/* Scratch bytes of skp_cross_attn_bwd_f32 (token-major staging of P and dS); negative on bad arguments. */
+int64_t skp_cross_attn_bwd_workspace(int B, int H, int N, int T);
+/* Backward: dq [B,N,H*d] and dk, dv [B,T,H*d] are WRITTEN (per batch row; the caller sums dk/dv over b
+ * when Bk == 1).  Deterministic (no atomics). */
+int skp_cross_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
+                           const float* dout, const float* lse, float* dq, float* dk, float* dv,
+                           float* workspace, int B, int Bk, int H, int N, int T, int d, float scale,
+                           void* stream);
 
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects

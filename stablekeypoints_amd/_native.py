@@ -32,7 +32,8 @@ SIGNATURES = {
     "skp_losses_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, C.POINTER(_f), _vp, _vp, _vp, _vp, _vp],
     "skp_rows_axpy_f32": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
     "skp_cross_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "skp_cross_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_cross_attn_bwd_workspace": [_i, _i, _i, _i],
+    "skp_cross_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "skp_self_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "skp_self_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
 }
@@ -60,7 +61,7 @@ def lib():
     l = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         if not hasattr(l, name):
-            if name.startswith(("skp_cross_attn", "skp_self_attn")):
+            if name.startswith("skp_self_attn"):
                 continue                       # optional until built (declared in skp.h only when present)
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}")
         fn = getattr(l, name)

@@ -229,3 +229,56 @@ class LossesFn(torch.autograd.Function):
 def fused_losses(M, Mt, sel, argmax, theta, sigma: float, num_subjects: int = 1):
     """theta: the FORWARD 2x3 affine of this image (6 floats, row-major). -> (sharp, equiv)."""
     return LossesFn.apply(M, Mt, sel, argmax, invert_affine(theta), float(sigma), int(num_subjects))
+
+
+# ---------------------------------------------------------------------------------------------
+# ordinary cross-attention core (short key axis)                 ptp_utils.py:493-506,540
+# ---------------------------------------------------------------------------------------------
+CROSS_ATTN_HEAD_DIMS = (8, 16, 40, 80, 160)
+CROSS_ATTN_MAX_T = 128
+
+
+def cross_attn_supported(C: int, heads: int, T: int) -> bool:
+    return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS and T <= CROSS_ATTN_MAX_T
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """out[b,n,:] = merge_heads(softmax(scale q k^T) v); q [B,N,C], k,v [Bk,T,C] (Bk in {1,B}) -> [B,N,C]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads: int, scale: float):
+        q, k, v = _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
+        B, Nq, C = q.shape
+        Bk, T, _ = k.shape
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
+        N.check(N.lib().skp_cross_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                               B, Bk, heads, Nq, T, C // heads, float(scale), _stream()),
+                "skp_cross_attn_fwd_f32")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.meta = (heads, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        heads, scale = ctx.meta
+        dout = _dev(dout, "dout")
+        B, Nq, C = q.shape
+        Bk, T, _ = k.shape
+        dq = torch.empty_like(q)
+        dk = torch.empty(B, T, C, device=q.device, dtype=torch.float32)
+        dv = torch.empty_like(dk)
+        nbytes = N.lib().skp_cross_attn_bwd_workspace(B, heads, Nq, T)
+        ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+        N.check(N.lib().skp_cross_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                               lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(),
+                                               B, Bk, heads, Nq, T, C // heads, scale, _stream()),
+                "skp_cross_attn_bwd_f32")
+        if Bk == 1 and B > 1:
+            dk, dv = dk.sum(dim=0, keepdim=True), dv.sum(dim=0, keepdim=True)
+        return dq, dk, dv, None, None
+
+
+def cross_attention(q, k, v, heads: int, scale: float):
+    return CrossAttnFn.apply(q, k, v, int(heads), float(scale))

@@ -26,6 +26,7 @@ def load_ldm(device, type="CompVis/stable-diffusion-v1-4", feature_upsample_res=
     controllers = {dev: ptp_utils.AttentionStore()}
     # patched once: the module tree is never re-replicated (cf. the forward-pre-hook of optimize_token.py:60-69)
     ptp_utils.register_attention_control(ldm.unet, controllers[dev], feature_upsample_res=feature_upsample_res)
+    ptp_utils.accelerate_cross_attention(ldm.unet)     # down/mid cross layers: same fused core, never stored
     for module in (ldm.vae, ldm.text_encoder, ldm.unet):
         for p in module.parameters():
             p.requires_grad = False

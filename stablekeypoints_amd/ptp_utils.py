@@ -86,11 +86,12 @@ MAX_STORED_LAYERS = 4          # ptp_utils.py:511
 MAX_STORED_SEQ = 32 ** 2       # ptp_utils.py:510
 
 
-def _attention_core(module, q, k, v):
-    """softmax(scale q k^T) v per head (ptp_utils.py:493-506) on [B,N,C]/[B,T,C] tensors."""
-    fused = getattr(module, "_skp_fused_core", None)
-    if fused is not None:
-        return fused(q, k, v, module.heads, module.scale)
+def _attention_core(module, q, k, v, is_cross=False):
+    """softmax(scale q k^T) v per head (ptp_utils.py:493-506) on [B,N,C]/[B,T,C] tensors.  Cross layers with
+    a short key axis run on the fused fp32-MFMA kernel (csrc/skp_cross_attn.hip); self-attention keeps the
+    library path of the frozen network."""
+    if is_cross and q.is_cuda and ops.cross_attn_supported(q.shape[-1], module.heads, k.shape[1]):
+        return ops.cross_attention(q, k, v, module.heads, module.scale)
     qh = module.reshape_heads_to_batch_dim(q)
     kh = module.reshape_heads_to_batch_dim(k)
     vh = module.reshape_heads_to_batch_dim(v)
@@ -116,7 +117,7 @@ def register_attention_control(model, controller, feature_upsample_res=256):
             ctx = context if is_cross else x
             k = self.to_k(ctx)
             v = self.to_v(ctx)
-            out = _attention_core(self, q, k, v)
+            out = _attention_core(self, q, k, v, is_cross)
             if (is_cross and sequence_length <= MAX_STORED_SEQ
                     and len(controller.step_store["attn"]) < MAX_STORED_LAYERS):
                 rec = FusedAttn(q, k, self.heads, self.scale, feature_upsample_res)
@@ -157,6 +158,22 @@ def register_attention_control(model, controller, feature_upsample_res=256):
     controller.num_att_layers = cross_att_count
     assert cross_att_count != 0, ("No cross attention layers found in the model. The module tree must use the "
                                   "diffusers==0.8.0 `CrossAttention` layout.")
+
+
+def accelerate_cross_attention(net):
+    """Route the UNPATCHED (down/mid) cross-attention layers through the same fused kernel; they never store
+    maps (the reference only hooks `up` blocks, ptp_utils.py:565-568) so only their `forward` core changes."""
+    for mod in net.modules():
+        if mod.__class__.__name__ == "CrossAttention" and "forward" not in mod.__dict__:
+            def make(m):
+                to_out = m.to_out[0] if isinstance(m.to_out, torch.nn.ModuleList) else m.to_out
+
+                def forward(x, context=None, mask=None):
+                    is_cross = context is not None
+                    ctx = context if is_cross else x
+                    return to_out(_attention_core(m, m.to_q(x), m.to_k(ctx), m.to_v(ctx), is_cross))
+                return forward
+            mod.forward = make(mod)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -202,3 +202,28 @@ def test_sd_shape_maps_invariants(ops):
         torch.testing.assert_close(M.sum(1), torch.ones(B, 128, 128, device="cuda"), rtol=1e-5, atol=1e-5)
         M1 = ops.attn_map([q[1:2] for q in qs], ks, 8, scales, 128)
         torch.testing.assert_close(M1[0], M[1], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("B,Bk,N,H,d,T", [(2, 1, 256, 8, 160, 77), (1, 1, 100, 4, 8, 16), (2, 2, 1024, 8, 80, 77),
+                                          (1, 1, 4096, 8, 40, 100), (3, 1, 64, 2, 16, 5)])
+def test_cross_attention_fwd_bwd_vs_fp64(ops, B, Bk, N, H, d, T):
+    """Fused fp32-MFMA cross-attention (ptp_utils.py:493-506) against the reference formulation in fp64."""
+    g = torch.Generator().manual_seed(11)
+    C = H * d
+    q = torch.randn(B, N, C, generator=g)
+    k = torch.randn(Bk, T, C, generator=g)
+    v = torch.randn(Bk, T, C, generator=g)
+    w = torch.randn(B, N, C, generator=g)
+    scale = d ** -0.5
+    qd, kd, vd = (x.double().requires_grad_(True) for x in (q, k, v))
+    qh = R.split_heads(qd, H)
+    kh = R.split_heads(kd.expand(B, -1, -1), H)
+    vh = R.split_heads(vd.expand(B, -1, -1), H)
+    ref = R.merge_heads(torch.matmul((torch.einsum("bid,bjd->bij", qh, kh) * scale).softmax(-1), vh), H)
+    (ref * w.double()).sum().backward()
+    qg, kg, vg = (x.cuda().requires_grad_(True) for x in (q, k, v))
+    out = ops.cross_attention(qg, kg, vg, H, scale)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    (out * w.cuda()).sum().backward()
+    for a, b in ((qg, qd), (kg, kd), (vg, vd)):
+        torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-3, atol=2e-5 * b.grad.abs().max().item())
