@@ -67,9 +67,20 @@ int skp_qk_logits_f32(const float* q, const float* k, float* S, int B, int Bk, i
  * M:   [B, T, R, R]            (written)
  * lse: [B, L*H, R*R]           (written; log2-sum-exp per (layer, head, pixel), needed by _bwd)
  * S[l]: [B, H, s[l]*s[l], NT] (layout of skp_qk_logits_f32).
- * Limits: 1 <= T <= 128, L <= SKP_MAX_LAYERS, s[l] <= 64, R <= 4096.  */
+ * Limits: 1 <= T <= 128 (more tokens: skp_attn_map_fwd_ex_f32), L <= SKP_MAX_LAYERS, s[l] <= 64, R <= 2048.  */
 int skp_attn_map_fwd_f32(const float* const* S /*[host] L device ptrs*/, const int* s /*[host] L*/,
                          int L, int B, int H, int T, int R, float* M, float* lse, void* stream);
+
+/* Token-group form of the forward for T > 128 learned tokens (the reference CLI default is 500, main.py:77-79).
+ * The launch covers T (<= 128) tokens whose column offset the caller has folded into the S[l] and M pointers;
+ * ldt = row stride of the logits (floats, multiple of 4), m_bstride = floats between batch rows of M.
+ *   mode 0: self-contained (== skp_attn_map_fwd_f32)
+ *   mode 1: statistics only -- writes this group's log2-sum-exp to lse_out, M untouched
+ *   mode 2: apply -- P = exp2(S - lse_in) against the log2-sum-exp over ALL groups (caller combines the
+ *           per-group values: lse = log2 sum_g 2^lse_g), writes this group's rows of M */
+int skp_attn_map_fwd_ex_f32(const float* const* S /*[host]*/, const int* s /*[host]*/, int L, int B, int H,
+                            int T, int R, float* M, float* lse_out, const float* lse_in, int ldt,
+                            int64_t m_bstride, int mode, void* stream);
 
 /* Bytes of scratch skp_attn_map_bwd_f32 needs (staging of the horizontally-reduced gradient between its
  * two kernels); negative on bad arguments. */
@@ -97,6 +108,13 @@ int skp_cross_attn_bwd_f32(const float* q, const float* k, const float* v, const
                            const float* dout, const float* lse, float* dq, float* dk, float* dv,
                            float* workspace, int B, int Bk, int H, int N, int T, int d, float scale,
                            void* stream);
+
+/* Token-group form of the backward.  mode 1: writes dot_io[b,l*H+h,p] = sum_{t in group} P*dM/(L*H) only;
+ * mode 2: reads dot_io = that sum over ALL groups and writes this group's columns of dS[l]; mode 0 as above.
+ * lse is always the log2-sum-exp over all tokens. */
+int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/,
+                            int L, int B, int H, int T, int R, const float* dM, const float* lse,
+                            float* workspace, float* dot_io, int ldt, int64_t m_bstride, int mode, void* stream);
 
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects

@@ -35,6 +35,10 @@ struct MapArgs {
     int TH, TW, segs, smax;        // tile rows, tile width, segments per row, max layer side
     int vt_floats;                 // floats of the Vt buffer
     float inv_lh;
+    // token-group extension (T > 128): the launch covers tokens [t0, t0+T) of a wider problem
+    int ldt;                       // row stride (floats) of S / dS rows (>= NT of this launch)
+    long m_bstride;                // floats between batch rows of M / dM
+    int mode;                      // 0 self-contained | 1 statistics only | 2 apply external statistics
 };
 
 // lane -> pixel of the row-aligned tile
@@ -60,7 +64,7 @@ __device__ __forceinline__ Tile skp_tile(const MapArgs& a, int blk, int tid) {
 template <int NT>
 __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float* __restrict__ Vt,
                                             const int* __restrict__ tab_cy, const float* __restrict__ tab_wy,
-                                            int s, int rc, int tid) {
+                                            int s, int rc, int tid, int ldt) {
     constexpr int TS = NT + 1, Q = NT / 4;
     const float inv_s = 1.0f / (float)s;
     const int items = rc * Q;
@@ -72,7 +76,7 @@ __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float*
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * NT + q4 * 4);
+            const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * ldt + q4 * 4);
             acc += tab_wy[row * 4 + j] * v;
         }
         float* o = Vt + r * TS + q4 * 4;
@@ -80,14 +84,15 @@ __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float*
     }
 }
 
-template <int NT>
+template <int NT, int MODE>
 __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float* __restrict__ M,
-                                                               float* __restrict__ lse_out) {
+                                                               float* __restrict__ lse_out,
+                                                               const float* __restrict__ lse_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TS = NT + 1;
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, b = blockIdx.x;            // batch row fastest: workgroup id % 8 (XCD) == b % 8
     const int R = a.R, T = a.T, H = a.H, RR = R * R;
-    const Tile tl = skp_tile(a, blockIdx.x, tid);
+    const Tile tl = skp_tile(a, blockIdx.y, tid);
     const int p = (tl.y0 + tl.ry) * R + tl.x;
     float* Vt = smem;
     int* tab_cy = (int*)(smem + a.vt_floats);
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
         }
         const int rc = tl.th_eff * s;
         for (int h = 0; h < H; ++h, ++lh) {
-            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * NT;
+            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * a.ldt;
             __syncthreads();                                   // tables ready / previous H phase done
-            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid);
+            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid, a.ldt);
             __syncthreads();
             float sv[NT];
             float m = -INFINITY;
@@ -130,34 +135,43 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
                 sv[t] = (t < T) ? v : -INFINITY;
                 m = fmaxf(m, sv[t]);
             }
+            const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
+            if (MODE == 2) {                                   // probabilities against the GLOBAL log-sum-exp
+                const float lse = tl.valid ? lse_in[li] : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] += __builtin_amdgcn_exp2f(sv[t] - lse);
+                continue;
+            }
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) { sv[t] = __builtin_amdgcn_exp2f(sv[t] - m); sum += sv[t]; }
-            const float inv = 1.0f / sum;
+            if (MODE == 0) {
+                const float inv = 1.0f / sum;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = fmaf(sv[t], inv, acc[t]);
-            if (tl.valid) lse_out[((size_t)b * a.L * H + lh) * RR + p] = m + __builtin_amdgcn_logf(sum);
+                for (int t = 0; t < NT; ++t) acc[t] = fmaf(sv[t], inv, acc[t]);
+            }
+            if (tl.valid) lse_out[li] = m + __builtin_amdgcn_logf(sum);
         }
     }
-    if (tl.valid) {
+    if (tl.valid && MODE != 1) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (t < T) M[((size_t)b * T + t) * RR + p] = acc[t] * a.inv_lh;
+            if (t < T) M[(size_t)b * a.m_bstride + (size_t)t * RR + p] = acc[t] * a.inv_lh;
     }
 }
 
 // Backward, kernel A.  LDS: Vt | dSx[256][TC+1] | Wt[smax][TW] | xlo[smax] xhi[smax] | row tables.
-template <int NT>
+template <int NT, int MODE>
 __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const float* __restrict__ dM,
                                                                const float* __restrict__ lse_in,
-                                                               float* __restrict__ dV) {
+                                                               float* __restrict__ dV, float* __restrict__ dot_io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TS = NT + 1;
     constexpr int NCH = (NT > 48) ? 2 : 1;                     // the transpose buffer holds NT/NCH tokens at a time
     constexpr int TC = NT / NCH, TSC = TC + 1, TQ = TC / 4;
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, b = blockIdx.x;            // batch row fastest: workgroup id % 8 (XCD) == b % 8
     const int R = a.R, T = a.T, H = a.H, RR = R * R;
-    const Tile tl = skp_tile(a, blockIdx.x, tid);
+    const Tile tl = skp_tile(a, blockIdx.y, tid);
     const int p = (tl.y0 + tl.ry) * R + tl.x;
     const int xl = tl.x - tl.seg * 256;                        // column inside the tile
     float* Vt = smem;
@@ -170,7 +184,8 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
 
     float g[NT];                                               // dM / (L*H), lane-local
 #pragma unroll
-    for (int t = 0; t < NT; ++t) g[t] = (tl.valid && t < T) ? dM[((size_t)b * T + t) * RR + p] * a.inv_lh : 0.f;
+    for (int t = 0; t < NT; ++t)
+        g[t] = (tl.valid && t < T) ? dM[(size_t)b * a.m_bstride + (size_t)t * RR + p] * a.inv_lh : 0.f;
 
     int lh = 0;
     for (int l = 0; l < a.L; ++l) {
@@ -202,11 +217,12 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
         const int rc = tl.th_eff * s;
         const float inv_s = 1.0f / (float)s;
         for (int h = 0; h < H; ++h, ++lh) {
-            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * NT;
+            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * a.ldt;
             __syncthreads();                                   // tables/Wt ready; previous gather done
-            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid);
+            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid, a.ldt);
             __syncthreads();
-            const float lse = tl.valid ? lse_in[((size_t)b * a.L * H + lh) * RR + p] : 0.f;
+            const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
+            const float lse = tl.valid ? lse_in[li] : 0.f;
             float sv[NT];
             float dot = 0.f;
 #pragma unroll
@@ -218,6 +234,8 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
                 sv[t] = (t < T) ? __builtin_amdgcn_exp2f(v - lse) : 0.f;
                 dot = fmaf(sv[t], g[t], dot);
             }
+            if (MODE == 1) { if (tl.valid) dot_io[li] = dot; continue; }   // statistics pass of a token group
+            if (MODE == 2) dot = tl.valid ? dot_io[li] : 0.f;               // sum over ALL token groups
             float* dVg = dV + (size_t)b * a.dv_per_b + a.dv_off[l] +
                          ((size_t)h * R + tl.y0) * a.segs * s * NT;          // [h][y][seg][c][t]
 #pragma unroll
@@ -261,14 +279,15 @@ struct VAdjArgs {
     int blk_off[SKP_MAX_LAYERS + 1];   // first block of layer l
     long dv_per_b;
     int L, H, R, segs, NT;
+    int ldt;                           // row stride of dS (floats)
 };
 
 __global__ __launch_bounds__(256) void skp_attn_map_vadj_kernel(VAdjArgs a, const float* __restrict__ dV) {
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, b = blockIdx.x;
     int l = 0;
-    while (l + 1 < a.L && (int)blockIdx.x >= a.blk_off[l + 1]) ++l;
+    while (l + 1 < a.L && (int)blockIdx.y >= a.blk_off[l + 1]) ++l;
     const int s = a.s[l], NT = a.NT, Q = NT / 4, R = a.R;
-    const int rel = blockIdx.x - a.blk_off[l];
+    const int rel = blockIdx.y - a.blk_off[l];
     const int h = rel / s, cy = rel - h * s;
     const float ratio = (float)s / (float)R;
     // rows y whose taps can touch cy: src(y) in (cy-2.5, cy+2.5) (+ everything beyond the clamped borders)
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_vadj_kernel(VAdjArgs a, cons
     if (cy == s - 1) yhi = R - 1;
     ylo = ylo < 0 ? 0 : ylo; yhi = yhi > R - 1 ? R - 1 : yhi;
     const float* dVg = dV + (size_t)b * a.dv_per_b + a.dv_off[l] + (size_t)h * R * a.segs * s * NT;
-    float* out = a.dS[l] + (((size_t)b * a.H + h) * s * s + (size_t)cy * s) * NT;
+    float* out = a.dS[l] + (((size_t)b * a.H + h) * s * s + (size_t)cy * s) * a.ldt;
     // each thread owns up to MAXI float4 slots (it = c*Q + q4: contiguous floats of one dV row)
     constexpr int MAXI = 8;                                    // s <= 64, NT <= 128 => s*Q <= 2048 = 8*256
     const int nit = s * Q;
@@ -302,8 +321,8 @@ __global__ __launch_bounds__(256) void skp_attn_map_vadj_kernel(VAdjArgs a, cons
     }
 #pragma unroll
     for (int u = 0; u < MAXI; ++u) {
-        const int it = tid + u * 256;
-        if (it < nit) *(f32x4*)(out + it * 4) = acc[u];
+        const int it = tid + u * 256;                           // it = c*Q + q4
+        if (it < nit) { const int c = it / Q, q4 = it - c * Q; *(f32x4*)(out + (size_t)c * a.ldt + q4 * 4) = acc[u]; }
     }
 }
 
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_vadj_kernel(VAdjArgs a, cons
 static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const int* s, int L, int B, int H,
                      int T, int R) {
     if (!S || !s || L <= 0 || B <= 0 || H <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
-    if (L > SKP_MAX_LAYERS || T > 128 || B > 65535 || R > 4096) return SKP_E_RANGE;
+    if (L > SKP_MAX_LAYERS || T > 128 || R > 4096) return SKP_E_RANGE;
     const int nt = ((T + 15) / 16) * 16;
     int smax = 0;
     long off = 0;
@@ -347,27 +366,47 @@ static int n_tiles(const MapArgs& a) { return a.R <= 256 ? (a.R + a.TH - 1) / a.
         default: return SKP_E_RANGE;                                                                    \
     }
 
-extern "C" int skp_attn_map_fwd_f32(const float* const* S, const int* s, int L, int B, int H, int T, int R,
-                                    float* M, float* lse, void* stream) {
+static int n_tiles_ok(const MapArgs& a) { return n_tiles(a) <= 65535; }
+
+// Extended entry points: the launch covers T tokens starting at column offset folded into the S/dS/M/dM
+// pointers by the caller; `ldt` = logits row stride, `m_bstride` = floats between batch rows of M/dM.
+extern "C" int skp_attn_map_fwd_ex_f32(const float* const* S, const int* s, int L, int B, int H, int T, int R,
+                                       float* M, float* lse_out, const float* lse_in, int ldt,
+                                       int64_t m_bstride, int mode, void* stream) {
     MapArgs a{};
     int rc = fill_args(a, S, nullptr, s, L, B, H, T, R);
     if (rc) return rc;
-    if (!M || !lse) return SKP_E_BADARG;
     const int nt = ((T + 15) / 16) * 16;
+    if (mode < 0 || mode > 2 || ldt < nt || (ldt & 3)) return SKP_E_BADARG;
+    if ((mode != 1 && !M) || (mode != 2 && !lse_out) || (mode == 2 && !lse_in)) return SKP_E_BADARG;
+    if (!n_tiles_ok(a)) return SKP_E_RANGE;
+    a.ldt = ldt; a.m_bstride = m_bstride; a.mode = mode;
     const size_t lds = ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
     if (lds > 160 * 1024) return SKP_E_LDS;
-    dim3 grid(n_tiles(a), B), block(256);
+    dim3 grid(B, n_tiles(a)), block(256);
     hipStream_t st = (hipStream_t)stream;
+#define SKP_FWD_M(NTV, MD)                                                                               \
+    {                                                                                                    \
+        if (lds > 64 * 1024) {                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_fwd_kernel<NTV, MD>,            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+            if (e != hipSuccess) return (int)e;                                                          \
+        }                                                                                                \
+        hipLaunchKernelGGL((skp_attn_map_fwd_kernel<NTV, MD>), grid, block, lds, st, a, M, lse_out, lse_in); \
+    }
 #define SKP_FWD(NTV)                                                                                     \
-    if (lds > 64 * 1024) {                                                                               \
-        hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_fwd_kernel<NTV>,                    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        if (e != hipSuccess) return (int)e;                                                              \
-    }                                                                                                    \
-    hipLaunchKernelGGL((skp_attn_map_fwd_kernel<NTV>), grid, block, lds, st, a, M, lse);
+    if (mode == 0) SKP_FWD_M(NTV, 0) else if (mode == 1) SKP_FWD_M(NTV, 1) else SKP_FWD_M(NTV, 2)
     SKP_NT_SWITCH(nt, SKP_FWD)
 #undef SKP_FWD
+#undef SKP_FWD_M
     return skp_launch_status();
+}
+
+extern "C" int skp_attn_map_fwd_f32(const float* const* S, const int* s, int L, int B, int H, int T, int R,
+                                    float* M, float* lse, void* stream) {
+    if (T > 128 || T <= 0 || R <= 0) return T > 128 ? SKP_E_RANGE : SKP_E_BADARG;
+    return skp_attn_map_fwd_ex_f32(S, s, L, B, H, T, R, M, lse, nullptr, ((T + 15) / 16) * 16,
+                                   (int64_t)T * R * R, 0, stream);
 }
 
 extern "C" int64_t skp_attn_map_bwd_workspace(const int* s, int L, int B, int H, int T, int R) {
@@ -379,32 +418,40 @@ extern "C" int64_t skp_attn_map_bwd_workspace(const int* s, int L, int B, int H,
     return fl * B * (int64_t)sizeof(float);
 }
 
-extern "C" int skp_attn_map_bwd_f32(const float* const* S, float* const* dS, const int* s, int L, int B, int H,
-                                    int T, int R, const float* dM, const float* lse, float* workspace,
-                                    void* stream) {
+extern "C" int skp_attn_map_bwd_ex_f32(const float* const* S, float* const* dS, const int* s, int L, int B, int H,
+                                       int T, int R, const float* dM, const float* lse, float* workspace,
+                                       float* dot_io, int ldt, int64_t m_bstride, int mode, void* stream) {
     MapArgs a{};
     if (!dS) return SKP_E_BADARG;
     int rc = fill_args(a, S, dS, s, L, B, H, T, R);
     if (rc) return rc;
-    if (!dM || !lse || !workspace) return SKP_E_BADARG;
     const int nt = ((T + 15) / 16) * 16;
+    if (!dM || !lse || !workspace || mode < 0 || mode > 2 || (mode != 0 && !dot_io) || ldt < nt || (ldt & 3))
+        return SKP_E_BADARG;
+    if (!n_tiles_ok(a)) return SKP_E_RANGE;
+    a.ldt = ldt; a.m_bstride = m_bstride; a.mode = mode;
     const int tc = nt > 48 ? nt / 2 : nt;
     const size_t lds = ((size_t)a.vt_floats + 256 * (size_t)(tc + 1) + (size_t)a.smax * a.TW + 2 * (size_t)a.smax +
                         8 * (size_t)a.TH) * sizeof(float);
     if (lds > 160 * 1024) return SKP_E_LDS;
-    dim3 grid(n_tiles(a), B), block(256);
+    dim3 grid(B, n_tiles(a)), block(256);
     hipStream_t st = (hipStream_t)stream;
+#define SKP_BWD_M(NTV, MD)                                                                               \
+    {                                                                                                    \
+        if (lds > 64 * 1024) {                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_bwd_kernel<NTV, MD>,            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+            if (e != hipSuccess) return (int)e;                                                          \
+        }                                                                                                \
+        hipLaunchKernelGGL((skp_attn_map_bwd_kernel<NTV, MD>), grid, block, lds, st, a, dM, lse, workspace, dot_io); \
+    }
 #define SKP_BWD(NTV)                                                                                     \
-    if (lds > 64 * 1024) {                                                                               \
-        hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_bwd_kernel<NTV>,                    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-        if (e != hipSuccess) return (int)e;                                                              \
-    }                                                                                                    \
-    hipLaunchKernelGGL((skp_attn_map_bwd_kernel<NTV>), grid, block, lds, st, a, dM, lse, workspace);
+    if (mode == 0) SKP_BWD_M(NTV, 0) else if (mode == 1) SKP_BWD_M(NTV, 1) else SKP_BWD_M(NTV, 2)
     SKP_NT_SWITCH(nt, SKP_BWD)
 #undef SKP_BWD
+#undef SKP_BWD_M
     rc = skp_launch_status();
-    if (rc) return rc;
+    if (rc || mode == 1) return rc;
     VAdjArgs v{};
     int nblk = 0;
     for (int l = 0; l < L; ++l) {
@@ -412,7 +459,15 @@ extern "C" int skp_attn_map_bwd_f32(const float* const* S, float* const* dS, con
         nblk += H * a.s[l];
     }
     v.blk_off[L] = nblk;
-    v.dv_per_b = a.dv_per_b; v.L = L; v.H = H; v.R = R; v.segs = a.segs; v.NT = nt;
-    hipLaunchKernelGGL(skp_attn_map_vadj_kernel, dim3(nblk, B), dim3(256), 0, st, v, (const float*)workspace);
+    v.dv_per_b = a.dv_per_b; v.L = L; v.H = H; v.R = R; v.segs = a.segs; v.NT = nt; v.ldt = ldt;
+    hipLaunchKernelGGL(skp_attn_map_vadj_kernel, dim3(B, nblk), dim3(256), 0, st, v, (const float*)workspace);
     return skp_launch_status();
+}
+
+extern "C" int skp_attn_map_bwd_f32(const float* const* S, float* const* dS, const int* s, int L, int B, int H,
+                                    int T, int R, const float* dM, const float* lse, float* workspace,
+                                    void* stream) {
+    if (T > 128 || T <= 0 || R <= 0) return T > 128 ? SKP_E_RANGE : SKP_E_BADARG;
+    return skp_attn_map_bwd_ex_f32(S, dS, s, L, B, H, T, R, dM, lse, workspace, nullptr, ((T + 15) / 16) * 16,
+                                   (int64_t)T * R * R, 0, stream);
 }

@@ -146,30 +146,47 @@ __global__ __launch_bounds__(256) void skp_select_kernel(const float* __restrict
         cand_out[tid] = tok;
     }
     __syncthreads();
-    if (tid != 0) return;
-    int chosen[SKP_SEL_MAXC];                                   // candidate slots
-    int nch = 0;
+    if (tid >= 64) return;                                      // one wave finishes the selection
+    // lane c (< n_cand) owns candidate slot c.  Tie rules of the reference's python loops (strict '>' in
+    // ascending scan order => the FIRST maximum wins) are kept by (value desc, index asc) wave reductions.
+    const int lane = tid;
+    const bool act = lane < n_cand;
+    const float my_y = act ? s_ly[lane] : 0.f, my_x = act ? s_lx[lane] : 0.f;
     float best = -1.0f; int ba = 0, bb = 1;
-    for (int i = 0; i < n_cand; ++i)                            // ptp_utils.py:132-137
-        for (int j = i + 1; j < n_cand; ++j) {
-            const float d = skp_dist(s_ly[i], s_lx[i], s_ly[j], s_lx[j]);
-            if (d > best) { best = d; ba = i; bb = j; }
+    for (int i = 0; i + 1 < n_cand; ++i) {                      // ptp_utils.py:132-137
+        float d = (act && lane > i) ? skp_dist(s_ly[i], s_lx[i], my_y, my_x) : -INFINITY;
+        int j = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(d, o, 64); const int oj = __shfl_xor(j, o, 64);
+            if (skp_better(od, oj, d, j)) { d = od; j = oj; }
         }
-    chosen[nch++] = ba; chosen[nch++] = bb;
-    for (int it = 0; it < top_k - 2; ++it) {                    // ptp_utils.py:142-157
-        float far = -1.0f; int fi = -1;
-        for (int i = 0; i < n_cand; ++i) {
-            bool taken = false;
-            for (int q = 0; q < nch; ++q) taken |= (s_cand[chosen[q]] == s_cand[i]);
-            if (taken) continue;
-            float dmin = INFINITY;
-            for (int q = 0; q < nch; ++q)
-                dmin = fminf(dmin, skp_dist(s_ly[i], s_lx[i], s_ly[chosen[q]], s_lx[chosen[q]]));
-            if (dmin > far) { far = dmin; fi = i; }
-        }
-        if (fi >= 0) chosen[nch++] = fi;
+        if (d > best) { best = d; ba = i; bb = j; }
     }
-    for (int q = 0; q < top_k; ++q) sel_out[q] = (q < nch) ? (int64_t)s_cand[chosen[q]] : (int64_t)s_cand[chosen[nch - 1]];
+    // greedy max-min: keep each candidate's distance to the chosen set incrementally (min is exact, so this
+    // equals the reference's recomputation over all selected points)
+    int nch = 2;
+    int mine = (lane == 0) ? ba : bb;                           // lane q remembers the q-th chosen slot
+    bool taken = act && (lane == ba || lane == bb);
+    float dmin = fminf(skp_dist(my_y, my_x, __shfl(my_y, ba, 64), __shfl(my_x, ba, 64)),
+                       skp_dist(my_y, my_x, __shfl(my_y, bb, 64), __shfl(my_x, bb, 64)));
+    for (int it = 0; it < top_k - 2; ++it) {                    // ptp_utils.py:142-157
+        float d = (act && !taken) ? dmin : -INFINITY;
+        int j = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(d, o, 64); const int oj = __shfl_xor(j, o, 64);
+            if (skp_better(od, oj, d, j)) { d = od; j = oj; }
+        }
+        if (d > -1.0f) {                                        // `this_min_dist > max_min_dist` starting from -1
+            if (lane == nch) mine = j;
+            if (lane == j) taken = true;
+            dmin = fminf(dmin, skp_dist(my_y, my_x, __shfl(my_y, j, 64), __shfl(my_x, j, 64)));
+            ++nch;
+        }
+    }
+    const int last = __shfl(mine, nch - 1, 64);
+    if (lane < top_k) sel_out[lane] = (int64_t)s_cand[lane < nch ? mine : last];
 }
 
 extern "C" int skp_select_tokens(const float* kl, const int32_t* argmax_t, int T, int R, int n_cand, int top_k,
@@ -297,4 +314,4 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 2; }
+extern "C" int skp_abi_version(void) { return 3; }

@@ -48,15 +48,77 @@ def _gemm_nt(A, B, Cout, M, Nn, K, Z0, Z1, sa, sb, sc, alpha):
                                     *sa, *sb, *sc, float(alpha), _stream()), "skp_gemm_nt_f32")
 
 
+TOKEN_GROUP = 128          # most tokens one fused-map launch can hold (one softmax row per lane, in registers)
+GROUP_STEP = 96            # group width when T > TOKEN_GROUP (NT=96 instantiation: no register spills)
+
+
+def _groups(T: int):
+    return [(t0, min(T, t0 + GROUP_STEP)) for t0 in range(0, T, GROUP_STEP)]
+
+
+def _log2sumexp2(xs: List[torch.Tensor]) -> torch.Tensor:
+    st = torch.stack(xs, 0)
+    m = st.max(dim=0).values
+    return m + torch.log2(torch.exp2(st - m).sum(dim=0))
+
+
 def _map_fwd(S: Sequence[torch.Tensor], sides: Sequence[int], B: int, H: int, T: int, R: int):
+    """-> (M [B,T,R,R], lse [B,L*H,R*R] log2-sum-exp over all tokens).  T > 128 runs token groups in two
+    passes (group statistics -> combine -> apply)."""
     dev = S[0].device
+    L, ldt = len(S), S[0].shape[-1]
     M = torch.empty(B, T, R, R, device=dev, dtype=torch.float32)
-    lse = torch.empty(B, len(S) * H, R * R, device=dev, dtype=torch.float32)
-    sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
     si, _k2 = N.int_array(sides)
-    N.check(N.lib().skp_attn_map_fwd_f32(sp, si, len(S), B, H, T, R, M.data_ptr(), lse.data_ptr(), _stream()),
-            "skp_attn_map_fwd_f32")
+    lib, st = N.lib(), _stream()
+
+    def launch(t0, t1, mode, lse_out, lse_in):
+        sp, _k1 = N.ptr_array([t.data_ptr() + 4 * t0 for t in S])
+        N.check(lib.skp_attn_map_fwd_ex_f32(sp, si, L, B, H, t1 - t0, R, M.data_ptr() + 4 * t0 * R * R,
+                                            lse_out.data_ptr() if lse_out is not None else None,
+                                            lse_in.data_ptr() if lse_in is not None else None,
+                                            ldt, T * R * R, mode, st), "skp_attn_map_fwd_ex_f32")
+
+    if T <= TOKEN_GROUP:
+        lse = torch.empty(B, L * H, R * R, device=dev, dtype=torch.float32)
+        launch(0, T, 0, lse, None)
+        return M, lse
+    parts = []
+    for t0, t1 in _groups(T):
+        parts.append(torch.empty(B, L * H, R * R, device=dev, dtype=torch.float32))
+        launch(t0, t1, 1, parts[-1], None)
+    lse = _log2sumexp2(parts)
+    for t0, t1 in _groups(T):
+        launch(t0, t1, 2, None, lse)
     return M, lse
+
+
+def _map_bwd(S, dS, sides, B, H, T, R, dM, lse):
+    dev = dM.device
+    L, ldt = len(S), S[0].shape[-1]
+    si, _k3 = N.int_array(sides)
+    lib, st = N.lib(), _stream()
+    nbytes = lib.skp_attn_map_bwd_workspace(si, L, B, H, T if T <= TOKEN_GROUP else GROUP_STEP, R)
+    if nbytes < 0:
+        N.check(int(nbytes), "skp_attn_map_bwd_workspace")
+    ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+
+    def launch(t0, t1, mode, dot):
+        sp, _k1 = N.ptr_array([t.data_ptr() + 4 * t0 for t in S])
+        dp, _k2 = N.ptr_array([t.data_ptr() + 4 * t0 for t in dS])
+        N.check(lib.skp_attn_map_bwd_ex_f32(sp, dp, si, L, B, H, t1 - t0, R, dM.data_ptr() + 4 * t0 * R * R,
+                                            lse.data_ptr(), ws.data_ptr(), dot.data_ptr() if dot is not None else None,
+                                            ldt, T * R * R, mode, st), "skp_attn_map_bwd_ex_f32")
+
+    if T <= TOKEN_GROUP:
+        launch(0, T, 0, None)
+        return
+    dots = []
+    for t0, t1 in _groups(T):
+        dots.append(torch.empty(B, L * H, R * R, device=dev, dtype=torch.float32))
+        launch(t0, t1, 1, dots[-1])
+    dot = torch.stack(dots, 0).sum(dim=0)
+    for t0, t1 in _groups(T):
+        launch(t0, t1, 2, dot)
 
 
 class AttnMapFn(torch.autograd.Function):
@@ -90,16 +152,10 @@ class AttnMapFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         lse, qs, ks, S = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:]
         dM = _dev(dM, "dM")
-        dS = [torch.empty_like(s_) for s_ in S]
-        sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
-        dp, _k2 = N.ptr_array([t.data_ptr() for t in dS])
-        si, _k3 = N.int_array(sides)
-        nbytes = N.lib().skp_attn_map_bwd_workspace(si, L, B, H, T, R)
-        if nbytes < 0:
-            N.check(int(nbytes), "skp_attn_map_bwd_workspace")
-        ws = torch.empty(nbytes // 4, device=dM.device, dtype=torch.float32)
-        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, L, B, H, T, R, dM.data_ptr(), lse.data_ptr(),
-                                             ws.data_ptr(), _stream()), "skp_attn_map_bwd_f32")
+        # pad columns (t >= T) of a LAST partial group are written as 0 by the kernels; zero-fill covers the
+        # (never read) gap columns when T > 128 is not a multiple of 16
+        dS = [torch.empty_like(s_) if T <= TOKEN_GROUP else torch.zeros_like(s_) for s_ in S]
+        _map_bwd(S, dS, sides, B, H, T, R, dM, lse)
         grads: List[torch.Tensor] = []
         for l in range(L):
             q, k, ds, sc = qs[l], ks[l], dS[l], scales[l]

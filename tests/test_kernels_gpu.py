@@ -227,3 +227,34 @@ def test_cross_attention_fwd_bwd_vs_fp64(ops, B, Bk, N, H, d, T):
     (out * w.cuda()).sum().backward()
     for a, b in ((qg, qd), (kg, kd), (vg, vd)):
         torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-3, atol=2e-5 * b.grad.abs().max().item())
+
+
+def test_many_tokens_grouped_path_matches_fp64(ops):
+    """T = 300 learned tokens (reference CLI default is 500): token-group two-pass path, fwd + bwd."""
+    c = STACK_CASE
+    heads, Rr, T, B = c["heads"], 32, 300, 2
+    g = torch.Generator().manual_seed(9)
+    qs = [torch.randn(B, sl * sl, Cl, generator=g) for sl, Cl in c["layers"]]
+    ks = [torch.randn(1, T, Cl, generator=g) for sl, Cl in c["layers"]]
+    W = torch.randn(B, T, Rr, Rr, generator=g)
+    scales = [(Cl // heads) ** -0.5 for _, Cl in c["layers"]]
+    qd = [q.double().requires_grad_(True) for q in qs]
+    kd = [k.double().requires_grad_(True) for k in ks]
+    maps = []
+    for q, k, (sl, Cl), sc in zip(qd, kd, c["layers"], scales):
+        qi = q.reshape(B, sl, sl, Cl).permute(0, 3, 1, 2)
+        qu = torch.nn.functional.interpolate(qi, size=(Rr, Rr), mode="bicubic", align_corners=False)
+        qu = R.split_heads(qu.permute(0, 2, 3, 1).reshape(B, Rr * Rr, Cl), heads)
+        kk = R.split_heads(k.expand(B, -1, -1), heads)
+        p = (torch.einsum("bid,bjd->bij", qu, kk) * sc).softmax(-1)
+        maps.append(p.reshape(B, heads, Rr, Rr, T).permute(0, 1, 4, 2, 3))
+    Mref = torch.stack(maps, 0).mean(dim=(0, 2))
+    (Mref * W.double()).sum().backward()
+    qg = [q.cuda().requires_grad_(True) for q in qs]
+    kg = [k.cuda().requires_grad_(True) for k in ks]
+    M = ops.attn_map(qg, kg, heads, scales, Rr)
+    torch.testing.assert_close(M.detach().cpu().double(), Mref.detach(), rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(M.sum(1), torch.ones(B, Rr, Rr, device="cuda"), rtol=1e-5, atol=1e-5)
+    (M * W.cuda()).sum().backward()
+    for a, b in zip(qg + kg, qd + kd):
+        torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=2e-3, atol=2e-5 * b.grad.abs().max().item())
