@@ -118,6 +118,24 @@ def cpu_baseline(ldm_cpu, args):
                       f"T={args.tokens}, R={args.res}, torch {torch.__version__} CPU fp32, {sec:.1f} s"}
 
 
+def measured_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*.json, separate
+    FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at the same launch shape; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md 'HBM').  None when no profile is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels_*.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        for name, c in k.items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
+    return None
+
+
 def main():
     a = parse()
     from stablekeypoints_amd import dist as D
@@ -126,6 +144,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # host threads: N ranks share the box's cores (weight init + the Python driver are the only CPU work)
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(1, world))))
     from stablekeypoints_amd import ops, _native
     from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
     from stablekeypoints_amd.optimize import SyntheticImages, default_args, group_step
@@ -204,9 +224,9 @@ def main():
                                    f"T={a.tokens} tokens, R={a.res}, top_k=10 of 25, fp32 end to end",
                        "global_batch": global_batch, "images_per_rank": per_rank, "tokens": a.tokens,
                        "feature_upsample_res": a.res, "parallelism": f"dp{world}"},
-            "roofline": {"kernel": "skp_attn_map_kernel<80,false> (fused up-res softmax map, forward)",
+            "roofline": {"kernel": "skp_attn_map_fwd_kernel<80,0> (fused up-res softmax map, forward)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("skp_attn_map_fwd_kernel"),
                          "launch_us": kt["fwd"] * 1e6, "algorithmic_bytes": fwd_bytes, "rows_per_launch": B,
                          "bwd_launch_us": kt["bwd"] * 1e6, "bwd_achieved": bwd_bytes / kt["bwd"] / 1e9,
                          "reference_contraction_equiv_tflops": flops_equiv / kt["fwd"] / 1e12,

@@ -61,6 +61,10 @@ E2E_CASE = dict(layers=[(4, 64), (4, 64), (4, 64), (8, 32)], heads=4, T=24, ctx_
                 n_cand=10, top_k=4, sigma=2.0, seed=51)
 
 
+# G8/G9: the reference's driver functions on the reduced-width SD-topology model ("tiny", seed 0).
+TINY_CASE = dict(size=128, T=16, R=32, n_cand=8, top_k=4, sigma=2.0, seed=61, aug_iters=3, upscale=64)
+
+
 def selection_maps():
     """Two [T,R,R] non-negative maps with sum_t == 1 per pixel, some peaky tokens, and an exact
     two-way tie (pins the first-index argmax rule)."""

@@ -31,3 +31,62 @@ def mask_radius(map, max_coords, radius):
     ys = torch.arange(h, device=map.device).view(1, h, 1)
     d2 = (xs - max_coords[:, 1].view(b, 1, 1)) ** 2 + (ys - max_coords[:, 0].view(b, 1, 1)) ** 2
     return map * (d2 > radius ** 2).float()
+
+
+def pixel_from_weighted_avg(heatmaps, distance=5):
+    """eval.py:113-155: intensity-weighted mean location within `distance` px of the arg-max (+0.5);
+    like the reference this ZEROES the far pixels of `heatmaps` in place."""
+    b, m, n = heatmaps.shape
+    if distance != -1:
+        mx = find_max_pixel(heatmaps)
+        x_max, y_max = mx[:, 0].long(), mx[:, 1].long()
+        x = torch.arange(0, m, device=heatmaps.device).float().view(1, m, 1)
+        y = torch.arange(0, n, device=heatmaps.device).float().view(1, 1, n)
+        dist = torch.sqrt((x - x_max.view(b, 1, 1)) ** 2 + (y - y_max.view(b, 1, 1)) ** 2)
+        heatmaps[dist > distance] = 0.0
+    total = torch.sum(heatmaps, dim=[1, 2], keepdim=True)
+    norm = heatmaps / (total + 1e-6)
+    x = torch.arange(0, m, device=heatmaps.device).float().view(1, m, 1)
+    y = torch.arange(0, n, device=heatmaps.device).float().view(1, 1, n)
+    return torch.stack([torch.sum(x * norm, dim=[1, 2]), torch.sum(y * norm, dim=[1, 2])], dim=-1) + 0.5
+
+
+@torch.no_grad()
+def run_image_with_context_augmented(ldm, image, context, indices, device="cuda",
+                                     from_where=["down_cross", "mid_cross", "up_cross"], layers=[0, 1, 2, 3, 4, 5],
+                                     augmentation_iterations=20, noise_level=-1, augment_degrees=30,
+                                     augment_scale=(0.9, 1.1), augment_translate=(0.1, 0.1), visualize=False,
+                                     controllers=None, num_gpus=1, save_folder="outputs", upscale_size=512,
+                                     thetas=None, noise=None):
+    """eval.py:197-355: maps of the selected tokens averaged over random affine views of ONE image.
+
+    Reference loop: per augmentation -> UNet forward -> collect_maps(indices, upsample_res=upscale_size) ->
+    inverse-warp the maps and a ones-mask -> accumulate; result = sum/count with NaN -> 0.
+    Here all `augmentation_iterations // num_gpus` views go through the network as ONE batch (early exit,
+    fused map kernel); gather/resize/unwarp stay linear ops applied after the layer/head mean.
+    `thetas` [n,2,3] / `noise` [n,4,h,w] let a caller inject the random draws (parity tests)."""
+    import numpy as np
+    from . import ptp_utils
+    from ._maps import collect_maps_batched
+    from .invertable_transform import RandomAffineWithInverse
+    import torch.nn.functional as F
+
+    if visualize:
+        raise NotImplementedError("plotting is out of scope (SURVEY.md 2.1 row 14)")
+    dev, controller = next(iter(controllers.items()))
+    if isinstance(image, np.ndarray):
+        image = torch.from_numpy(image).permute(2, 0, 1)
+    image = image.to(device=dev, dtype=torch.float32)
+    n = augmentation_iterations // num_gpus
+    tr = RandomAffineWithInverse(degrees=augment_degrees, scale=augment_scale, translate=augment_translate)
+    views = tr(image[None].repeat(n, 1, 1, 1), theta=thetas)
+    ptp_utils.find_pred_noise(ldm, views, context.to(dev), noise_level=noise_level, device=dev, noise=noise,
+                              early_exit=True, controllers={dev: controller})
+    maps = collect_maps_batched(controller, layers=layers)                  # [n,T,R,R]
+    idx = torch.as_tensor(indices, device=dev).long()
+    maps = F.interpolate(maps[:, idx], size=(upscale_size, upscale_size), mode="bilinear", align_corners=False)
+    num = tr.inverse(torch.ones_like(maps)).sum(dim=0)
+    tot = tr.inverse(maps).sum(dim=0)
+    out = tot / num
+    out[out != out] = 0
+    return out

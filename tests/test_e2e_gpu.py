@@ -106,3 +106,62 @@ def test_optimize_embedding_runs_and_decreases_loss():
     assert out.shape == (1, 16, 768) and not out.requires_grad and torch.isfinite(out).all()
     step = (out.cpu() - ctx0).abs().max().item()
     assert 0 < step <= 3 * 5e-3 * 1.01                                     # 3 Adam steps of lr 5e-3
+
+
+def test_g8_fused_step_vs_reference_driver_golden(golden=None):
+    """The fused MI355X step against golden values produced by the REFERENCE's own driver functions
+    (run_and_find_attn, find_top_k_gaussian, furthest_point_sampling, sharpening/equivariance loss, backward)
+    on the same reduced-width model (tests/golden/g8_reference_step_tiny.npz)."""
+    import numpy as np, os
+    from oracle.fixtures import TINY_CASE as tc, seeded
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import default_args, group_step
+    from stablekeypoints_amd.optimize_token import load_ldm
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_reference_step_tiny.npz")))
+    ldm, controllers, _ = load_ldm("cuda", "tiny", feature_upsample_res=tc["R"])
+    dev, controller = next(iter(controllers.items()))
+    image = torch.rand(1, 3, tc["size"], tc["size"], generator=torch.Generator().manual_seed(tc["seed"]))
+    ctx = seeded((1, tc["T"], 768), tc["seed"] + 1).cuda().requires_grad_(True)
+    args = default_args(num_tokens=tc["T"], feature_upsample_res=tc["R"], furthest_point_num_samples=tc["n_cand"],
+                        top_k=tc["top_k"], sigma=tc["sigma"], batch_size=1)
+    loss, eq, sh = group_step(ldm, image, ctx, args, controller, RandomAffineWithInverse(), denom=1,
+                              noise=torch.from_numpy(g["noise"]).cuda(), thetas=torch.from_numpy(g["theta"]))
+    assert abs(sh.item() - float(g["sharp"])) < 1e-3 * abs(float(g["sharp"]))
+    assert abs(eq.item() - float(g["equiv"])) < 2e-3 * abs(float(g["equiv"]))
+    ref = torch.from_numpy(g["context_grad"])
+    torch.testing.assert_close(ctx.grad.cpu(), ref, rtol=5e-3, atol=5e-5 * ref.abs().max().item())
+
+
+def test_g9_augmented_inference_and_keypoints_vs_reference_golden():
+    """run_image_with_context_augmented + arg-max keypoints against the reference's eval.py output (G9)."""
+    import numpy as np, os
+    from oracle.fixtures import TINY_CASE as tc, seeded
+    from stablekeypoints_amd.eval import run_image_with_context_augmented
+    from stablekeypoints_amd.keypoint_regressor import keypoints_from_maps
+    from stablekeypoints_amd.optimize_token import load_ldm
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_reference_augmented_tiny.npz")))
+    ldm, controllers, _ = load_ldm("cuda", "tiny", feature_upsample_res=tc["R"])
+    image = torch.rand(1, 3, tc["size"], tc["size"], generator=torch.Generator().manual_seed(tc["seed"]))[0]
+    ctx = seeded((1, tc["T"], 768), tc["seed"] + 1).cuda()
+    maps = run_image_with_context_augmented(
+        ldm, image.permute(1, 2, 0).numpy(), ctx, torch.from_numpy(g["indices"]), device="cuda", layers=[0, 1, 2, 3],
+        augmentation_iterations=tc["aug_iters"], augment_degrees=30, augment_scale=(0.9, 1.1),
+        augment_translate=(0.1, 0.1), controllers=controllers, num_gpus=1, upscale_size=tc["upscale"],
+        thetas=torch.from_numpy(g["thetas"]), noise=torch.from_numpy(g["noise"]).cuda())
+    ref = torch.from_numpy(g["maps"])
+    assert maps.shape == ref.shape
+    torch.testing.assert_close(maps.cpu(), ref, rtol=1e-3, atol=1e-6)
+    kp = keypoints_from_maps(maps, "argmax").cpu()
+    assert torch.equal(kp, torch.from_numpy(g["keypoints"]))               # final keypoint locations, bit-exact
+
+
+def test_find_best_indices_runs():
+    from stablekeypoints_amd.keypoint_regressor import find_best_indices
+    from stablekeypoints_amd.optimize import default_args
+    from stablekeypoints_amd.optimize_token import load_ldm
+    ldm, controllers, n = load_ldm("cuda", "tiny", feature_upsample_res=32)
+    args = default_args(num_tokens=16, feature_upsample_res=32, furthest_point_num_samples=8, top_k=4, image_size=128,
+                        max_len=6, device="cuda", num_indices=6)
+    idx = find_best_indices(ldm, torch.randn(1, 16, 768, generator=torch.Generator().manual_seed(2)).cuda(), args,
+                            controllers, n)
+    assert idx.shape == (4,) and idx.dtype == torch.int64 and len(set(idx.tolist())) == 4 and idx.max() < 16

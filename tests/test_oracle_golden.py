@@ -166,3 +166,29 @@ def test_scheduler_restatement():
     assert ts[-1].item() == 0 and ts[0].item() == 980 and len(ts) == 50
     acp = R.ddim_alphas_cumprod()
     assert abs(acp[0].item() - (1 - 0.00085)) < 1e-7
+
+
+def test_g8_oracle_full_step_vs_reference_driver(golden):
+    """The oracle's CPU step (oracle/cpu_path.py) against the REFERENCE's own run_and_find_attn / selection /
+    losses / backward, both driving the same reduced-width SD-topology module tree (G8)."""
+    from oracle import cpu_path
+    from oracle.fixtures import TINY_CASE as tc
+    from stablekeypoints_amd.optimize_token import load_ldm
+    g = golden("g8_reference_step_tiny.npz")
+    ldm, _, _ = load_ldm("cpu", "tiny", feature_upsample_res=tc["R"])
+    store = R.OracleStore()
+    cpu_path.register_reference_hook(ldm.unet, store, tc["R"])
+    image = torch.rand(1, 3, tc["size"], tc["size"], generator=torch.Generator().manual_seed(tc["seed"]))
+    ctx = seeded((1, tc["T"], 768), tc["seed"] + 1).requires_grad_(True)
+    noise = t(g["noise"])
+    loss, sharp, equiv, sel, am, am_t = cpu_path.image_step(
+        ldm, image, ctx, store, t(g["theta"]), noise[0:1], noise[1:2],
+        furthest_point_num_samples=tc["n_cand"], top_k=tc["top_k"], sigma=tc["sigma"])
+    torch.testing.assert_close(am, t(g["map"]), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(am_t, t(g["map_t"]), rtol=1e-4, atol=1e-7)
+    assert torch.equal(sel, t(g["sel"]))
+    assert abs(sharp.item() - float(g["sharp"])) < 1e-5 * abs(float(g["sharp"]))
+    assert abs(equiv.item() - float(g["equiv"])) < 1e-4 * abs(float(g["equiv"]))
+    loss.backward()
+    ref = t(g["context_grad"])
+    torch.testing.assert_close(ctx.grad, ref, rtol=1e-3, atol=1e-5 * ref.abs().max().item())
