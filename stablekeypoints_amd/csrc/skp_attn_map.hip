@@ -24,6 +24,7 @@
 //                 transpose + gather (deterministic, no atomics) -> dV[y][seg][c][t] in HBM
 //   second backward kernel: vertical adjoint dS[cy][c][t] = sum_y Wy(y,cy) sum_seg dV[y][seg][c][t]
 #include "skp_common.h"
+#include <stdlib.h>
 
 struct MapArgs {
     const float* S[SKP_MAX_LAYERS];
@@ -65,7 +66,7 @@ template <int NT>
 __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float* __restrict__ Vt,
                                             const int* __restrict__ tab_cy, const float* __restrict__ tab_wy,
                                             int s, int rc, int tid, int ldt) {
-    constexpr int TS = NT + 1, Q = NT / 4;
+    constexpr int TS = NT + 2, Q = NT / 4;
     const float inv_s = 1.0f / (float)s;
     const int items = rc * Q;
 #pragma unroll 2
@@ -79,17 +80,18 @@ __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float*
             const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * ldt + q4 * 4);
             acc += tab_wy[row * 4 + j] * v;
         }
-        float* o = Vt + r * TS + q4 * 4;
-        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+        f32x2* o = (f32x2*)(Vt + r * TS + q4 * 4);
+        o[0] = f32x2{acc[0], acc[1]}; o[1] = f32x2{acc[2], acc[3]};
     }
 }
+
 
 template <int NT, int MODE>
 __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float* __restrict__ M,
                                                                float* __restrict__ lse_out,
                                                                const float* __restrict__ lse_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 1;
+    constexpr int TS = NT + 2;                                 // even: token pairs are 8-byte aligned (ds_read_b64)
     const int tid = threadIdx.x, b = blockIdx.x;            // batch row fastest: workgroup id % 8 (XCD) == b % 8
     const int R = a.R, T = a.T, H = a.H, RR = R * R;
     const Tile tl = skp_tile(a, blockIdx.y, tid);
@@ -98,9 +100,10 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
     int* tab_cy = (int*)(smem + a.vt_floats);
     float* tab_wy = (float*)(tab_cy + a.TH * 4);
 
-    float acc[NT];
+    constexpr int NP = NT / 2;
+    f32x2 acc[NP];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+    for (int u = 0; u < NP; ++u) acc[u] = f32x2{0.f, 0.f};
 
     int lh = 0;
     for (int l = 0; l < a.L; ++l) {
@@ -109,8 +112,149 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
         int cx[4]; float wx[4];
         skp_cubic_taps(tl.x, ratio, s, cx, wx);
         int base[4];
+        f32x2 w2[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) base[i] = (tl.ry * s + cx[i]) * TS;
+        for (int i = 0; i < 4; ++i) { base[i] = (tl.ry * s + cx[i]) * TS; w2[i] = f32x2{wx[i], wx[i]}; }
+        __syncthreads();                                       // previous layer done with the tables (and raw rows)
+        if (tid < tl.th_eff) {
+            int cy[4]; float wy[4];
+            skp_cubic_taps(tl.y0 + tid, ratio, s, cy, wy);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
+        }
+        const int rc = tl.th_eff * s;
+        for (int h = 0; h < H; ++h, ++lh) {
+            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * a.ldt;
+            __syncthreads();                                   // tables ready / previous H phase done
+            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid, a.ldt);
+            __syncthreads();
+            f32x2 sv[NP];
+            float m = -INFINITY;
+            // token pairs (v_pk_mul/v_pk_fma, 8-byte LDS reads), tap-major over blocks of UB pairs so that UB
+            // independent fma chains are in flight (dependent packed ops otherwise stall a 2-waves/SIMD kernel)
+            constexpr int UB = 4;
+#pragma unroll
+            for (int u0 = 0; u0 < NP; u0 += UB) {
+                f32x2 tv[4][UB];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < UB; ++k) tv[i][k] = *(const f32x2*)(Vt + base[i] + 2 * (u0 + k));
+                f32x2 v[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) v[k] = w2[0] * tv[0][k];
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < UB; ++k) v[k] = w2[i] * tv[i][k] + v[k];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    const int u = u0 + k;
+                    if (2 * u >= NT - 16) {                     // NT = 16*ceil(T/16): only the last 16 can be pads
+                        if (2 * u >= T) v[k][0] = -INFINITY;
+                        if (2 * u + 1 >= T) v[k][1] = -INFINITY;
+                    }
+                    sv[u] = v[k];
+                }
+                float mb = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
+                mb = fmaxf(mb, fmaxf(fmaxf(v[2][0], v[2][1]), fmaxf(v[3][0], v[3][1])));
+                m = fmaxf(m, mb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
+            if (MODE == 2) {                                   // probabilities against the GLOBAL log-sum-exp
+                const float lse = tl.valid ? lse_in[li] : 0.f;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const f32x2 e = sv[u] - lse;
+                    acc[u] += f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                }
+                continue;
+            }
+            f32x2 sum4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const f32x2 e = sv[u] - m;
+                sv[u] = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                sum4[u & 3] += sv[u];
+            }
+            const f32x2 sum2 = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+            const float sum = sum2[0] + sum2[1];
+            if (MODE == 0) {
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[u] = sv[u] * inv + acc[u];
+            }
+            if (tl.valid) lse_out[li] = m + __builtin_amdgcn_logf(sum);
+        }
+    }
+    if (tl.valid && MODE != 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < NT - 16 || t < T) M[(size_t)b * a.m_bstride + (size_t)t * RR + p] = acc[t >> 1][t & 1] * a.inv_lh;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward, MFMA H phase (main path).  The VALU kernel above reads 4 taps x 4 B from LDS per output and is
+// LDS-bandwidth bound (ablation in profiles/).  Here the horizontal interpolation of a 16-pixel block is the
+// matrix product  D[t][x] = sum_c V[t][c] * Wx[c][x]  on v_mfma_f32_16x16x4_f32 (exact fp32 fma chain):
+//   A[i=t][k=c] = Vt[row][c][t]   ONE ds_read_b32 per MFMA (256 outputs)  -> 1 B of LDS per output
+//   B[k=c][j=x] = Wx[c][x]        the block's (<= 8 column) bicubic weights, in registers per layer
+//   D: lane (x = lane&15) holds tokens 16*tt + 4*(lane>>4) + r  -> the softmax over tokens is in-register
+//      plus two cross-lane exchanges (lane^16, lane^32).
+// A wave owns 4 blocks of 16 consecutive pixels; requires R % 16 == 0 and s/R <= 1/4 (<= 8 columns per block).
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, float* __restrict__ M,
+                                                                    float* __restrict__ lse_out,
+                                                                    const float* __restrict__ lse_in) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TS = NT + 2, TT = NT / 16, PB = 4;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int R = a.R, T = a.T, H = a.H, RR = R * R;
+    const Tile tl = skp_tile(a, blockIdx.y, tid);              // tile geometry (y0, seg, th_eff) + V-phase roles
+    float* Vt = smem;
+    int* tab_cy = (int*)(smem + a.vt_floats);
+    float* tab_wy = (float*)(tab_cy + a.TH * 4);
+
+    int prow[PB], px[PB], pp[PB];                               // this lane's pixel in each of its 4 blocks
+    bool pv[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int lin = wave * 64 + pb * 16 + li;
+        if (R <= 256) { prow[pb] = lin / R; px[pb] = lin - prow[pb] * R; pv[pb] = prow[pb] < tl.th_eff; }
+        else { prow[pb] = 0; px[pb] = tl.seg * 256 + lin; pv[pb] = px[pb] < R; }
+        if (!pv[pb]) { prow[pb] = 0; px[pb] = (R <= 256) ? li : R - 16 + li; }
+        pp[pb] = (tl.y0 + prow[pb]) * R + px[pb];
+    }
+    f32x4 acc[PB][TT];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[pb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int lh = 0;
+    for (int l = 0; l < a.L; ++l) {
+        const int s = a.s[l];
+        const float ratio = (float)s / (float)R;
+        float wB[PB][2];                                        // B operand: weight of column (cbu + 4*ks + g) for pixel px
+        int arow[PB][2];                                        // A operand: LDS float offset of that column's token row
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            int cx[4]; float wx[4];
+            skp_cubic_taps(px[pb], ratio, s, cx, wx);
+            const int ix = (int)floorf(ratio * ((float)px[pb] + 0.5f) - 0.5f);
+            const int cbu = (int)floorf(ratio * ((float)(px[pb] - li) + 0.5f) - 0.5f) - 1;   // block's first (unclamped) column
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int cv = cbu + 4 * ks + g;               // virtual column of this lane's k-slot
+                const int i = cv - (ix - 1);
+                wB[pb][ks] = (i == 0) ? wx[0] : (i == 1) ? wx[1] : (i == 2) ? wx[2] : (i == 3) ? wx[3] : 0.f;
+                const int cc = cv < 0 ? 0 : (cv > s - 1 ? s - 1 : cv);
+                arow[pb][ks] = (prow[pb] * s + cc) * TS + li;
+            }
+        }
         __syncthreads();                                       // previous layer done with the tables
         if (tid < tl.th_eff) {
             int cy[4]; float wy[4];
@@ -124,39 +268,65 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
             __syncthreads();                                   // tables ready / previous H phase done
             skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid, a.ldt);
             __syncthreads();
-            float sv[NT];
-            float m = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float v = wx[0] * Vt[base[0] + t];
-                v = fmaf(wx[1], Vt[base[1] + t], v);
-                v = fmaf(wx[2], Vt[base[2] + t], v);
-                v = fmaf(wx[3], Vt[base[3] + t], v);
-                sv[t] = (t < T) ? v : -INFINITY;
-                m = fmaxf(m, sv[t]);
+            for (int pb = 0; pb < PB; ++pb) {
+                f32x4 sv[TT];
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[arow[pb][0] + 16 * tt], wB[pb][0], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[arow[pb][1] + 16 * tt], wB[pb][1], d, 0, 0, 0);
+                    sv[tt] = d;
+                }
+                if (TT * 16 > T) {                              // pads live in the last t-tile only
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((TT - 1) * 16 + 4 * g + r >= T) sv[TT - 1][r] = -INFINITY;
+                }
+                const size_t lidx = ((size_t)b * a.L * H + lh) * RR + pp[pb];
+                if (MODE == 2) {
+                    const float lse = pv[pb] ? lse_in[lidx] : 0.f;
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[pb][tt][r] += __builtin_amdgcn_exp2f(sv[tt][r] - lse);
+                    continue;
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+                    m = fmaxf(m, fmaxf(fmaxf(sv[tt][0], sv[tt][1]), fmaxf(sv[tt][2], sv[tt][3])));
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[tt][r] = __builtin_amdgcn_exp2f(sv[tt][r] - m);
+                    s4 += sv[tt];
+                }
+                float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                if (MODE == 0) {
+                    const float inv = 1.0f / sum;
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) acc[pb][tt] += sv[tt] * inv;
+                }
+                if (pv[pb] && g == 0) lse_out[lidx] = m + __builtin_amdgcn_logf(sum);
             }
-            const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
-            if (MODE == 2) {                                   // probabilities against the GLOBAL log-sum-exp
-                const float lse = tl.valid ? lse_in[li] : 0.f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] += __builtin_amdgcn_exp2f(sv[t] - lse);
-                continue;
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { sv[t] = __builtin_amdgcn_exp2f(sv[t] - m); sum += sv[t]; }
-            if (MODE == 0) {
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = fmaf(sv[t], inv, acc[t]);
-            }
-            if (tl.valid) lse_out[li] = m + __builtin_amdgcn_logf(sum);
         }
     }
-    if (tl.valid && MODE != 1) {
+    if (MODE != 1) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t < T) M[(size_t)b * a.m_bstride + (size_t)t * RR + p] = acc[t] * a.inv_lh;
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 16 * tt + 4 * g + r;
+                    if (pv[pb] && t < T) M[(size_t)b * a.m_bstride + (size_t)t * RR + pp[pb]] = acc[pb][tt][r] * a.inv_lh;
+                }
     }
 }
 
@@ -166,7 +336,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
                                                                const float* __restrict__ lse_in,
                                                                float* __restrict__ dV, float* __restrict__ dot_io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 1;
+    constexpr int TS = NT + 2;                                 // even: token pairs are 8-byte aligned (ds_read_b64)
     constexpr int NCH = (NT > 48) ? 2 : 1;                     // the transpose buffer holds NT/NCH tokens at a time
     constexpr int TC = NT / NCH, TSC = TC + 1, TQ = TC / 4;
     const int tid = threadIdx.x, b = blockIdx.x;            // batch row fastest: workgroup id % 8 (XCD) == b % 8
@@ -350,7 +520,7 @@ static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const 
     }
     a.dv_per_b = off;
     a.L = L; a.B = B; a.H = H; a.T = T; a.smax = smax;
-    a.vt_floats = a.TH * smax * (nt + 1);
+    a.vt_floats = a.TH * smax * (nt + 2);
     a.vt_floats = (a.vt_floats + 3) & ~3;
     a.inv_lh = 1.0f / (float)(L * H);
     return 0;
@@ -381,24 +551,32 @@ extern "C" int skp_attn_map_fwd_ex_f32(const float* const* S, const int* s, int 
     if ((mode != 1 && !M) || (mode != 2 && !lse_out) || (mode == 2 && !lse_in)) return SKP_E_BADARG;
     if (!n_tiles_ok(a)) return SKP_E_RANGE;
     a.ldt = ldt; a.m_bstride = m_bstride; a.mode = mode;
+    bool mfma = (R % 16) == 0;                                  // MFMA H phase: 16-pixel blocks, <= 8 columns per block
+    for (int l = 0; l < L; ++l) mfma = mfma && (4 * a.s[l] <= R);
+    // The MFMA H phase is correct but currently slower than the packed-VALU kernel (209 vs 161 us at the bench
+    // shape: un-pipelined operand reads, scalar softmax -- profiles/r01_map_fwd_variants.md); opt-in for A/B runs.
+    { const char* e = getenv("SKP_MAP_MFMA"); if (!(e && e[0] == '1')) mfma = false; }
     const size_t lds = ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
     if (lds > 160 * 1024) return SKP_E_LDS;
     dim3 grid(B, n_tiles(a)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define SKP_FWD_M(NTV, MD)                                                                               \
+#define SKP_FWD_K(KERNEL, NTV, MD)                                                                       \
     {                                                                                                    \
         if (lds > 64 * 1024) {                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_fwd_kernel<NTV, MD>,            \
+            hipError_t e = hipFuncSetAttribute((const void*)KERNEL<NTV, MD>,                             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
             if (e != hipSuccess) return (int)e;                                                          \
         }                                                                                                \
-        hipLaunchKernelGGL((skp_attn_map_fwd_kernel<NTV, MD>), grid, block, lds, st, a, M, lse_out, lse_in); \
+        hipLaunchKernelGGL((KERNEL<NTV, MD>), grid, block, lds, st, a, M, lse_out, lse_in);              \
     }
+#define SKP_FWD_M(NTV, MD)                                                                               \
+    if (mfma) SKP_FWD_K(skp_attn_map_fwd_mfma_kernel, NTV, MD) else SKP_FWD_K(skp_attn_map_fwd_kernel, NTV, MD)
 #define SKP_FWD(NTV)                                                                                     \
-    if (mode == 0) SKP_FWD_M(NTV, 0) else if (mode == 1) SKP_FWD_M(NTV, 1) else SKP_FWD_M(NTV, 2)
+    if (mode == 0) { SKP_FWD_M(NTV, 0) } else if (mode == 1) { SKP_FWD_M(NTV, 1) } else { SKP_FWD_M(NTV, 2) }
     SKP_NT_SWITCH(nt, SKP_FWD)
 #undef SKP_FWD
 #undef SKP_FWD_M
+#undef SKP_FWD_K
     return skp_launch_status();
 }
 

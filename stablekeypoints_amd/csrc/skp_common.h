@@ -9,6 +9,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static inline int skp_launch_status() {
     hipError_t e = hipGetLastError();
