@@ -35,6 +35,7 @@ struct MapArgs {
     int L, B, H, T, R;
     int TH, TW, segs, smax;        // tile rows, tile width, segments per row, max layer side
     int vt_floats;                 // floats of the Vt buffer
+    int TH2, TW2, segs2, vt2_floats;   // geometry of the 128-pixel tiles (two-lanes-per-pixel kernels)
     float inv_lh;
     // token-group extension (T > 128): the launch covers tokens [t0, t0+T) of a wider problem
     int ldt;                       // row stride (floats) of S / dS rows (>= NT of this launch)
@@ -66,7 +67,7 @@ template <int NT>
 __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float* __restrict__ Vt,
                                             const int* __restrict__ tab_cy, const float* __restrict__ tab_wy,
                                             int s, int rc, int tid, int ldt) {
-    constexpr int TS = NT + 2, Q = NT / 4;
+    constexpr int TS = NT + 4, Q = NT / 4;
     const float inv_s = 1.0f / (float)s;
     const int items = rc * Q;
 #pragma unroll 2
@@ -80,8 +81,7 @@ __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float*
             const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * ldt + q4 * 4);
             acc += tab_wy[row * 4 + j] * v;
         }
-        f32x2* o = (f32x2*)(Vt + r * TS + q4 * 4);
-        o[0] = f32x2{acc[0], acc[1]}; o[1] = f32x2{acc[2], acc[3]};
+        *(f32x4*)(Vt + r * TS + q4 * 4) = acc;
     }
 }
 
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
                                                                float* __restrict__ lse_out,
                                                                const float* __restrict__ lse_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 2;                                 // even: token pairs are 8-byte aligned (ds_read_b64)
+    constexpr int TS = NT + 4;                                 // token quads are 16-byte aligned (ds_read_b128)
     const int tid = threadIdx.x, b = blockIdx.x;            // batch row fastest: workgroup id % 8 (XCD) == b % 8
     const int R = a.R, T = a.T, H = a.H, RR = R * R;
     const Tile tl = skp_tile(a, blockIdx.y, tid);
@@ -132,34 +132,25 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
             float m = -INFINITY;
             // token pairs (v_pk_mul/v_pk_fma, 8-byte LDS reads), tap-major over blocks of UB pairs so that UB
             // independent fma chains are in flight (dependent packed ops otherwise stall a 2-waves/SIMD kernel)
-            constexpr int UB = 4;
+            // token quads: one ds_read_b128 per tap per 4 tokens (256 B/clk LDS form), packed fp32 math
 #pragma unroll
-            for (int u0 = 0; u0 < NP; u0 += UB) {
-                f32x2 tv[4][UB];
+            for (int q = 0; q < NT / 4; ++q) {
+                const f32x4 t0 = *(const f32x4*)(Vt + base[0] + 4 * q);
+                const f32x4 t1 = *(const f32x4*)(Vt + base[1] + 4 * q);
+                const f32x4 t2 = *(const f32x4*)(Vt + base[2] + 4 * q);
+                const f32x4 t3 = *(const f32x4*)(Vt + base[3] + 4 * q);
+                f32x4 v = wx[0] * t0;
+                v = wx[1] * t1 + v;
+                v = wx[2] * t2 + v;
+                v = wx[3] * t3 + v;
+                if (4 * q >= NT - 16) {                         // NT = 16*ceil(T/16): only the last 16 can be pads
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int k = 0; k < UB; ++k) tv[i][k] = *(const f32x2*)(Vt + base[i] + 2 * (u0 + k));
-                f32x2 v[UB];
-#pragma unroll
-                for (int k = 0; k < UB; ++k) v[k] = w2[0] * tv[0][k];
-#pragma unroll
-                for (int i = 1; i < 4; ++i)
-#pragma unroll
-                    for (int k = 0; k < UB; ++k) v[k] = w2[i] * tv[i][k] + v[k];
-#pragma unroll
-                for (int k = 0; k < UB; ++k) {
-                    const int u = u0 + k;
-                    if (2 * u >= NT - 16) {                     // NT = 16*ceil(T/16): only the last 16 can be pads
-                        if (2 * u >= T) v[k][0] = -INFINITY;
-                        if (2 * u + 1 >= T) v[k][1] = -INFINITY;
-                    }
-                    sv[u] = v[k];
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * q + e >= T) v[e] = -INFINITY;
                 }
-                float mb = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
-                mb = fmaxf(mb, fmaxf(fmaxf(v[2][0], v[2][1]), fmaxf(v[3][0], v[3][1])));
-                m = fmaxf(m, mb);
-                __builtin_amdgcn_sched_barrier(0);
+                sv[2 * q] = f32x2{v[0], v[1]};
+                sv[2 * q + 1] = f32x2{v[2], v[3]};
+                m = fmaxf(m, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
             }
             const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
             if (MODE == 2) {                                   // probabilities against the GLOBAL log-sum-exp
@@ -196,7 +187,162 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Forward, MFMA H phase (main path).  The VALU kernel above reads 4 taps x 4 B from LDS per output and is
+// Forward, two lanes per pixel (opt-in variant, SKP_MAP_LANES=2).  Same algorithm as skp_attn_map_fwd_kernel, but the token row of
+// a pixel is split over lane l (tokens [0, NT/2)) and lane l^32 (tokens [NT/2, NT)): 40+40 registers per lane
+// at T=77 instead of 80+80 => ~110 VGPRs => 4 waves/SIMD instead of 2, which is what hides the LDS-return and
+// barrier waits that leave the VALU pipe 63 % busy in the one-lane-per-pixel kernel (profiles/).  The softmax
+// needs two cross-lane exchanges per (layer, head).  Tiles are 128 pixels (wave = 32 pixels x 2 halves).
+struct Tile2 { int y0, seg, ry, x, th_eff; bool valid; };
+
+__device__ __forceinline__ Tile2 skp_tile2(const MapArgs& a, int blk, int tid) {
+    Tile2 t;
+    const int lin = (tid >> 6) * 32 + (tid & 31);              // pixel of this lane inside the 128-pixel tile
+    if (a.R <= 128) {
+        t.y0 = blk * a.TH2; t.seg = 0;
+        t.ry = lin / a.R; t.x = lin - t.ry * a.R;
+        t.th_eff = (a.R - t.y0 < a.TH2) ? a.R - t.y0 : a.TH2;
+        t.valid = t.ry < t.th_eff;
+    } else {
+        t.y0 = blk / a.segs2; t.seg = blk - t.y0 * a.segs2;
+        t.ry = 0; t.x = t.seg * 128 + lin; t.th_eff = 1;
+        t.valid = t.x < a.R;
+    }
+    if (!t.valid) { t.ry = 0; t.x = (a.R <= 128) ? 0 : a.R - 1; }
+    return t;
+}
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256, (NT <= 96 ? 3 : 2)) void skp_attn_map_fwd2_kernel(MapArgs a, float* __restrict__ M,
+                                                                float* __restrict__ lse_out,
+                                                                const float* __restrict__ lse_in) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TS = NT + 4, TPL = NT / 2, NP = TPL / 2;      // tokens per lane, token pairs per lane
+    constexpr int HB = 4;                                       // heads per V phase: one barrier pair per HB heads
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int half = (tid >> 5) & 1, toff = half * TPL;
+    const int R = a.R, T = a.T, H = a.H, RR = R * R;
+    const Tile2 tl = skp_tile2(a, blockIdx.y, tid);
+    const int p = (tl.y0 + tl.ry) * R + tl.x;
+    float* Vt = smem;
+    int* tab_cy = (int*)(smem + (size_t)HB * a.vt2_floats);
+    float* tab_wy = (float*)(tab_cy + a.TH2 * 4);
+
+    f32x2 acc[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) acc[u] = f32x2{0.f, 0.f};
+
+    int lh = 0;
+    for (int l = 0; l < a.L; ++l) {
+        const int s = a.s[l];
+        const float ratio = (float)s / (float)R;
+        int cx[4]; float wx[4];
+        skp_cubic_taps(tl.x, ratio, s, cx, wx);
+        int base[4];
+        f32x2 w2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { base[i] = (tl.ry * s + cx[i]) * TS + toff; w2[i] = f32x2{wx[i], wx[i]}; }
+        __syncthreads();                                       // previous layer done with the tables
+        if (tid < tl.th_eff) {
+            int cy[4]; float wy[4];
+            skp_cubic_taps(tl.y0 + tid, ratio, s, cy, wy);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
+        }
+        const int rc = tl.th_eff * s;
+        for (int h0 = 0; h0 < H; h0 += HB) {
+          const int nh = (H - h0 < HB) ? H - h0 : HB;
+          __syncthreads();                                     // tables ready / previous H phases done
+          {                                                    // V phase of nh heads at once (independent loads)
+            constexpr int Q = NT / 4;
+            const float inv_s = 1.0f / (float)s;
+            const int per = rc * Q, items = nh * per;
+            const float* S0 = a.S[l] + ((size_t)(b * H + h0) * s * s) * a.ldt;
+#pragma unroll 2
+            for (int it = tid; it < items; it += 256) {
+                const int hb = it / per, rem = it - hb * per;
+                const int r = rem / Q, q4 = rem - r * Q;
+                const int row = (int)(((float)r + 0.5f) * inv_s);
+                const int c = r - row * s;
+                const float* Sg = S0 + (size_t)hb * s * s * a.ldt;
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + jj] * s + c)) * a.ldt + q4 * 4);
+                    av += tab_wy[row * 4 + jj] * v;
+                }
+                *(f32x4*)(Vt + (size_t)hb * a.vt2_floats + r * TS + q4 * 4) = av;
+            }
+          }
+          __syncthreads();
+          for (int hb = 0; hb < nh; ++hb, ++lh) {
+            const float* Vh = Vt + (size_t)hb * a.vt2_floats;
+            f32x2 sv[NP];
+            float m = -INFINITY;
+            constexpr int UB = 2;
+#pragma unroll
+            for (int u0 = 0; u0 < NP; u0 += UB) {
+                f32x2 tv[4][UB];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < UB; ++k) tv[i][k] = *(const f32x2*)(Vh + base[i] + 2 * (u0 + k));
+                f32x2 v[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) v[k] = w2[0] * tv[0][k];
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < UB; ++k) v[k] = w2[i] * tv[i][k] + v[k];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    const int u = u0 + k;
+                    if (2 * u >= TPL - 16) {                    // pads only among the last 16 tokens (upper half)
+                        if (toff + 2 * u >= T) v[k][0] = -INFINITY;
+                        if (toff + 2 * u + 1 >= T) v[k][1] = -INFINITY;
+                    }
+                    sv[u] = v[k];
+                }
+                m = fmaxf(m, fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1])));
+            }
+            const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
+            if (MODE == 2) {                                   // probabilities against the GLOBAL log-sum-exp
+                const float lse = tl.valid ? lse_in[li] : 0.f;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const f32x2 e = sv[u] - lse;
+                    acc[u] += f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                }
+                continue;
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));               // the partner lane holds the other half of the row
+            f32x2 sum4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const f32x2 e = sv[u] - m;
+                sv[u] = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                sum4[u & 3] += sv[u];
+            }
+            const f32x2 sum2 = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+            float sum = sum2[0] + sum2[1];
+            sum += __shfl_xor(sum, 32, 64);
+            if (MODE == 0) {
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[u] = sv[u] * inv + acc[u];
+            }
+            if (tl.valid && half == 0) lse_out[li] = m + __builtin_amdgcn_logf(sum);
+          }
+        }
+    }
+    if (tl.valid && MODE != 1) {
+#pragma unroll
+        for (int t = 0; t < TPL; ++t)
+            if (toff + t < T) M[(size_t)b * a.m_bstride + (size_t)(toff + t) * RR + p] = acc[t >> 1][t & 1] * a.inv_lh;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward, MFMA H phase (opt-in variant).  The VALU kernel above reads 4 taps x 4 B from LDS per output and is
 // LDS-bandwidth bound (ablation in profiles/).  Here the horizontal interpolation of a 16-pixel block is the
 // matrix product  D[t][x] = sum_c V[t][c] * Wx[c][x]  on v_mfma_f32_16x16x4_f32 (exact fp32 fma chain):
 //   A[i=t][k=c] = Vt[row][c][t]   ONE ds_read_b32 per MFMA (256 outputs)  -> 1 B of LDS per output
@@ -209,7 +355,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
                                                                     float* __restrict__ lse_out,
                                                                     const float* __restrict__ lse_in) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 2, TT = NT / 16, PB = 4;
+    constexpr int TS = NT + 4, TT = NT / 16, PB = 4;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int R = a.R, T = a.T, H = a.H, RR = R * R;
@@ -336,7 +482,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
                                                                const float* __restrict__ lse_in,
                                                                float* __restrict__ dV, float* __restrict__ dot_io) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 2;                                 // even: token pairs are 8-byte aligned (ds_read_b64)
+    constexpr int TS = NT + 4;                                 // token quads are 16-byte aligned (ds_read_b128)
     constexpr int NCH = (NT > 48) ? 2 : 1;                     // the transpose buffer holds NT/NCH tokens at a time
     constexpr int TC = NT / NCH, TSC = TC + 1, TQ = TC / 4;
     const int tid = threadIdx.x, b = blockIdx.x;            // batch row fastest: workgroup id % 8 (XCD) == b % 8
@@ -520,8 +666,11 @@ static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const 
     }
     a.dv_per_b = off;
     a.L = L; a.B = B; a.H = H; a.T = T; a.smax = smax;
-    a.vt_floats = a.TH * smax * (nt + 2);
+    a.vt_floats = a.TH * smax * (nt + 4);
     a.vt_floats = (a.vt_floats + 3) & ~3;
+    if (R <= 128) { a.TH2 = 128 / R; a.TW2 = R; a.segs2 = 1; }
+    else { a.TH2 = 1; a.TW2 = 128; a.segs2 = (R + 127) / 128; }
+    a.vt2_floats = (a.TH2 * smax * (nt + 4) + 3) & ~3;
     a.inv_lh = 1.0f / (float)(L * H);
     return 0;
 }
@@ -556,9 +705,15 @@ extern "C" int skp_attn_map_fwd_ex_f32(const float* const* S, const int* s, int 
     // The MFMA H phase is correct but currently slower than the packed-VALU kernel (209 vs 161 us at the bench
     // shape: un-pipelined operand reads, scalar softmax -- profiles/r01_map_fwd_variants.md); opt-in for A/B runs.
     { const char* e = getenv("SKP_MAP_MFMA"); if (!(e && e[0] == '1')) mfma = false; }
-    const size_t lds = ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
+    // default: one lane per pixel (fastest measured); SKP_MAP_LANES=2 selects the two-lanes-per-pixel kernel
+    bool two = false;
+    { const char* e = getenv("SKP_MAP_LANES"); if (e && e[0] == '2' && !mfma) two = true; }
+    const int ntile = two ? (R <= 128 ? (R + a.TH2 - 1) / a.TH2 : R * a.segs2) : n_tiles(a);
+    if (ntile > 65535) return SKP_E_RANGE;
+    const size_t lds = two ? (4 * (size_t)a.vt2_floats + 8 * (size_t)a.TH2) * sizeof(float)
+                           : ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
     if (lds > 160 * 1024) return SKP_E_LDS;
-    dim3 grid(B, n_tiles(a)), block(256);
+    dim3 grid(B, ntile), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SKP_FWD_K(KERNEL, NTV, MD)                                                                       \
     {                                                                                                    \
@@ -570,7 +725,9 @@ extern "C" int skp_attn_map_fwd_ex_f32(const float* const* S, const int* s, int 
         hipLaunchKernelGGL((KERNEL<NTV, MD>), grid, block, lds, st, a, M, lse_out, lse_in);              \
     }
 #define SKP_FWD_M(NTV, MD)                                                                               \
-    if (mfma) SKP_FWD_K(skp_attn_map_fwd_mfma_kernel, NTV, MD) else SKP_FWD_K(skp_attn_map_fwd_kernel, NTV, MD)
+    if (mfma) SKP_FWD_K(skp_attn_map_fwd_mfma_kernel, NTV, MD)                                           \
+    else if (two) SKP_FWD_K(skp_attn_map_fwd2_kernel, NTV, MD)                                           \
+    else SKP_FWD_K(skp_attn_map_fwd_kernel, NTV, MD)
 #define SKP_FWD(NTV)                                                                                     \
     if (mode == 0) { SKP_FWD_M(NTV, 0) } else if (mode == 1) { SKP_FWD_M(NTV, 1) } else { SKP_FWD_M(NTV, 2) }
     SKP_NT_SWITCH(nt, SKP_FWD)
