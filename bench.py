@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-fuse-norms", action="store_true", help="A/B: keep ATen GroupNorm/SiLU in the frozen blocks")
     return ap.parse_args()
 
 
@@ -170,6 +171,10 @@ def main():
     controllers = {dev: controller}
     ptp_utils.register_attention_control(ldm.unet, controller, feature_upsample_res=a.res)
     ptp_utils.accelerate_cross_attention(ldm.unet)
+    if not a.no_fuse_norms:
+        from stablekeypoints_amd.ldm.fused import fuse_norms
+        fuse_norms(ldm.unet)
+        fuse_norms(ldm.vae)
     t_build = time.time() - t_build
 
     per_rank = a.images_per_rank

@@ -15,6 +15,7 @@
  *   skp_attn_map_fwd_f32 / _bwd_f32         ptp_utils.py:513-538 + optimize.py:27-79
  *                                           (bicubic up-res softmax map, per-head store, layer/head mean)
  *   skp_cross_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (ordinary softmax(QK^T)V, cross layers)
+ *   skp_group_norm_fwd_f32 / _bwd_f32       GroupNorm+SiLU of the hooked UNet / VAE forward (ptp_utils.py:227-229, 289-304)
  *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
  *   skp_select_tokens                       ptp_utils.py:110-112,115-159
  *   skp_losses_fwd_f32                      optimize.py:157-206, optimize_token.py:203-241,
@@ -115,6 +116,19 @@ int skp_cross_attn_bwd_f32(const float* q, const float* k, const float* v, const
 int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/,
                             int L, int B, int H, int T, int R, const float* dM, const float* lse,
                             float* workspace, float* dot_io, int ldt, int64_t m_bstride, int mode, void* stream);
+
+/* Fused GroupNorm (+ per-(sample,channel) offset) (+ SiLU) of the frozen UNet/VAE blocks (diffusers ResnetBlock2D:
+ * conv -> [+bias, + time embedding] -> GroupNorm -> SiLU), NCHW:
+ *   y[n,c,p] = act( ((x[n,c,p] + off[n,c]) - mean[n,g]) * rstd[n,g] * gamma[c] + beta[c] ),  act = SiLU if silu else id
+ * x, y: [N,C,HW] (HW % 4 == 0, C % G == 0, N*G <= 65535); off: [N,C] or NULL; mean, rstd: [N,G] written (for _bwd);
+ * workspace: N*G*64*3 floats. */
+int skp_group_norm_fwd_f32(const float* x, const float* off, const float* gamma, const float* beta, float* y,
+                           float* mean, float* rstd, float* workspace, int N, int C, int G, int HW, float eps,
+                           int silu, void* stream);
+/* dx [N,C,HW] = d loss / d x given dy (gamma/beta/off are frozen on this path). workspace as above. */
+int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma, const float* beta,
+                           const float* dy, const float* mean, const float* rstd, float* dx, float* workspace,
+                           int N, int C, int G, int HW, float eps, int silu, void* stream);
 
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects

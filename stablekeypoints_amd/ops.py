@@ -338,3 +338,51 @@ class CrossAttnFn(torch.autograd.Function):
 
 def cross_attention(q, k, v, heads: int, scale: float):
     return CrossAttnFn.apply(q, k, v, int(heads), float(scale))
+
+
+# ---------------------------------------------------------------------------------------------
+# fused GroupNorm (+offset) (+SiLU) of the frozen network's blocks
+# ---------------------------------------------------------------------------------------------
+def group_norm_supported(x: torch.Tensor, groups: int) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % groups == 0
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] * groups <= 65535)
+
+
+class GroupNormSiLUFn(torch.autograd.Function):
+    """y = act(GroupNorm(x + off[:, :, None, None])) with act = SiLU or identity; gamma/beta/off frozen."""
+
+    @staticmethod
+    def forward(ctx, x, off, gamma, beta, groups: int, eps: float, silu: bool):
+        x = _dev(x, "x")
+        Nn, C, Hh, Ww = x.shape
+        off_c = _dev(off.reshape(Nn, C), "off") if off is not None else None
+        y = torch.empty_like(x)
+        mean = torch.empty(Nn, groups, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(Nn * groups * 64 * 3, device=x.device, dtype=torch.float32)
+        N.check(N.lib().skp_group_norm_fwd_f32(x.data_ptr(), off_c.data_ptr() if off_c is not None else None,
+                                               gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), ws.data_ptr(), Nn, C, groups, Hh * Ww, float(eps),
+                                               int(silu), _stream()), "skp_group_norm_fwd_f32")
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(x, off_c if off_c is not None else x.new_empty(0), gamma, beta, mean, rstd)
+        ctx.meta = (groups, float(eps), bool(silu), off_c is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, off_c, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, eps, silu, has_off = ctx.meta
+        dy = _dev(dy, "dy")
+        Nn, C, Hh, Ww = x.shape
+        dx = torch.empty_like(x)
+        ws = torch.empty(Nn * groups * 64 * 3, device=x.device, dtype=torch.float32)
+        N.check(N.lib().skp_group_norm_bwd_f32(x.data_ptr(), off_c.data_ptr() if has_off else None, gamma.data_ptr(),
+                                               beta.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dx.data_ptr(), ws.data_ptr(), Nn, C, groups, Hh * Ww, eps, int(silu),
+                                               _stream()), "skp_group_norm_bwd_f32")
+        return dx, None, None, None, None, None, None
+
+
+def group_norm_silu(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
+    return GroupNormSiLUFn.apply(x, off, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)

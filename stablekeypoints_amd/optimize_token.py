@@ -27,6 +27,10 @@ def load_ldm(device, type="CompVis/stable-diffusion-v1-4", feature_upsample_res=
     # patched once: the module tree is never re-replicated (cf. the forward-pre-hook of optimize_token.py:60-69)
     ptp_utils.register_attention_control(ldm.unet, controllers[dev], feature_upsample_res=feature_upsample_res)
     ptp_utils.accelerate_cross_attention(ldm.unet)     # down/mid cross layers: same fused core, never stored
+    if dev.type == "cuda":                              # GroupNorm(+bias/temb offset)+SiLU of the frozen blocks, fused
+        from .ldm.fused import fuse_norms
+        fuse_norms(ldm.unet)
+        fuse_norms(ldm.vae)
     for module in (ldm.vae, ldm.text_encoder, ldm.unet):
         for p in module.parameters():
             p.requires_grad = False

@@ -258,3 +258,28 @@ def test_many_tokens_grouped_path_matches_fp64(ops):
     (M * W.cuda()).sum().backward()
     for a, b in zip(qg + kg, qd + kd):
         torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=2e-3, atol=2e-5 * b.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("N,C,G,H,W,silu,with_off", [(2, 64, 32, 16, 16, True, True), (8, 320, 32, 64, 64, True, True),
+                                                      (1, 128, 32, 40, 24, False, False), (3, 32, 32, 6, 6, True, False),
+                                                      (2, 512, 32, 128, 128, True, False)])
+def test_fused_group_norm_silu_fwd_bwd(ops, N, C, G, H, W, silu, with_off):
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.7)
+    off = torch.randn(N, C, generator=g) if with_off else None
+    norm = torch.nn.GroupNorm(G, C, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g)); norm.bias.copy_(torch.randn(C, generator=g))
+    w = torch.randn(N, C, H, W, generator=g)
+    xd = x.double().requires_grad_(True)
+    nd = torch.nn.GroupNorm(G, C, eps=1e-5).double()
+    nd.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    z = nd(xd + (off.double()[:, :, None, None] if with_off else 0))
+    ref = torch.nn.functional.silu(z) if silu else z
+    (ref * w.double()).sum().backward()
+    norm = norm.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = ops.group_norm_silu(xg, norm, off=off.cuda() if with_off else None, silu=silu)
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    (y * w.cuda()).sum().backward()
+    torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
