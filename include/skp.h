@@ -102,7 +102,7 @@ int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[h
 int skp_cross_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
                            int B, int Bk, int H, int N, int T, int d, float scale, void* stream);
 /* Scratch bytes of skp_cross_attn_bwd_f32 (token-major staging of P and dS); negative on bad arguments. */
-int64_t skp_cross_attn_bwd_workspace(int B, int H, int N, int T);
+int64_t skp_cross_attn_bwd_workspace(int B, int H, int N, int T, int d);
 /* Backward: dq [B,N,H*d] and dk, dv [B,T,H*d] are WRITTEN (per batch row; the caller sums dk/dv over b
  * when Bk == 1).  Deterministic (no atomics). */
 int skp_cross_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,

@@ -17,6 +17,15 @@
 #include "skp_common.h"
 
 #define SKP_LN2 0.6931471805599453f
+#define SKP_CA_KSPLIT_MAX 16
+
+int skp_gemm_nt_splitk(const float* A, const float* B, float* C, float* partial, int64_t c_elems, int ksplit,
+                       int M, int N, int K, int Z0, int Z1,
+                       int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
+                       int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
+                       int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream);
+
+static int ca_ksplit(int N) { int k = N / 256; return k < 1 ? 1 : (k > SKP_CA_KSPLIT_MAX ? SKP_CA_KSPLIT_MAX : k); }
 
 template <int D8, int TT>
 struct CAShape {
@@ -264,9 +273,10 @@ extern "C" int skp_cross_attn_tp(int T) {                      // padded token c
     return (tt <= 1 ? 1 : (tt <= 3 ? 3 : 4)) * 32;
 }
 
-extern "C" int64_t skp_cross_attn_bwd_workspace(int B, int H, int N, int T) {
-    if (B <= 0 || H <= 0 || N <= 0 || T <= 0 || T > 128) return SKP_E_BADARG;
-    return 2 * (int64_t)B * H * skp_cross_attn_tp(T) * N * (int64_t)sizeof(float);
+extern "C" int64_t skp_cross_attn_bwd_workspace(int B, int H, int N, int T, int d) {
+    if (B <= 0 || H <= 0 || N <= 0 || T <= 0 || T > 128 || d <= 0) return SKP_E_BADARG;
+    // token-major staging of P and dS  +  split-K partials of dk (dv reuses them)
+    return (2 * (int64_t)B * H * skp_cross_attn_tp(T) * N + (int64_t)ca_ksplit(N) * B * T * H * d) * (int64_t)sizeof(float);
 }
 
 extern "C" int skp_cross_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
@@ -293,9 +303,12 @@ extern "C" int skp_cross_attn_bwd_f32(const float* q, const float* k, const floa
     if (rc) return rc;
     const int64_t C = (int64_t)H * d;
     // dk[b,t,h*d+c] = scale * sum_n dS[b,h,t,n] q[b,n,h*d+c] ;  dv[b,t,h*d+c] = sum_n P[b,h,t,n] dout[b,n,h*d+c]
-    rc = skp_gemm_nt_f32(dSst, q, dk, T, d, N, B, H, (int64_t)H * TP * N, (int64_t)TP * N, N, 1,
-                         (int64_t)N * C, d, 1, C, (int64_t)T * C, d, C, scale, stream);
+    float* part = dSst + (size_t)B * H * TP * N;
+    const int ksp = ca_ksplit(N);
+    const int64_t celems = (int64_t)B * T * C;
+    rc = skp_gemm_nt_splitk(dSst, q, dk, part, celems, ksp, T, d, N, B, H, (int64_t)H * TP * N, (int64_t)TP * N, N, 1,
+                            (int64_t)N * C, d, 1, C, (int64_t)T * C, d, C, scale, stream);
     if (rc) return rc;
-    return skp_gemm_nt_f32(Pst, dout, dv, T, d, N, B, H, (int64_t)H * TP * N, (int64_t)TP * N, N, 1,
-                           (int64_t)N * C, d, 1, C, (int64_t)T * C, d, C, 1.0f, stream);
+    return skp_gemm_nt_splitk(Pst, dout, dv, part, celems, ksp, T, d, N, B, H, (int64_t)H * TP * N, (int64_t)TP * N, N, 1,
+                              (int64_t)N * C, d, 1, C, (int64_t)T * C, d, C, 1.0f, stream);
 }

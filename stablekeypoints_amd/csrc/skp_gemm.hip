@@ -9,6 +9,8 @@ struct GemmArgs {
     const float* A; const float* B; float* C;
     int M, N, K, Z1;
     int Nload;                 // rows of B that exist (n >= Nload reads as 0; still stored when n < N)
+    int ksplit, kchunk;        // split-K: blockIdx.z = (z0*Z1+z1)*ksplit + ks handles k in [ks*kchunk, ...)
+    int64_t part_stride;       // floats between the ksplit partial copies of C (0 when ksplit == 1)
     int64_t sa0, sa1, sam, sak;
     int64_t sb0, sb1, sbn, sbk;
     int64_t sc0, sc1, scm;
@@ -21,13 +23,15 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     const int n0 = (blockIdx.x * 2 + (wave & 1)) * 32;
     const int m0 = (blockIdx.y * 2 + (wave >> 1)) * 32;
     if (m0 >= g.M || n0 >= g.N) return;                       // wave-uniform
-    const int z0 = blockIdx.z / g.Z1, z1 = blockIdx.z - z0 * g.Z1;
+    const int zz = blockIdx.z / g.ksplit, ks = blockIdx.z - zz * g.ksplit;
+    const int z0 = zz / g.Z1, z1 = zz - z0 * g.Z1;
     const bool mv = (m0 + i) < g.M, nv = (n0 + i) < g.Nload, ns = (n0 + i) < g.N;
     const float* Ap = g.A + z0 * g.sa0 + z1 * g.sa1 + (int64_t)(mv ? m0 + i : 0) * g.sam + hi * g.sak;
     const float* Bp = g.B + z0 * g.sb0 + z1 * g.sb1 + (int64_t)(nv ? n0 + i : 0) * g.sbn + hi * g.sbk;
     f32x16 acc = {0};
-    const int K = g.K;
-    int k = 0;
+    const int kbeg = ks * g.kchunk;
+    const int K = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;     // kchunk is a multiple of 8
+    int k = kbeg;
     for (; k + 8 <= K; k += 8) {                               // 4 MFMAs per trip, loads issued first
         float a[4], b[4];
 #pragma unroll
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
-    float* Cp = g.C + z0 * g.sc0 + z1 * g.sc1;
+    float* Cp = g.C + (int64_t)ks * g.part_stride + z0 * g.sc0 + z1 * g.sc1;
     if (ns) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -62,9 +66,42 @@ static int gemm_launch(const float* A, const float* B, float* C, int M, int N, i
                        int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || Z0 <= 0 || Z1 <= 0) return SKP_E_BADARG;
     if ((int64_t)Z0 * Z1 > 65535) return SKP_E_RANGE;
-    GemmArgs g{A, B, C, M, N, K, Z1, Nload, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
+    GemmArgs g{A, B, C, M, N, K, Z1, Nload, 1, (K + 7) & ~7, 0, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
     dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1);
     hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    return skp_launch_status();
+}
+
+// out[i] = sum_{ks} part[ks*stride + i]   (fixed order => deterministic)
+__global__ __launch_bounds__(256) void skp_splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                int64_t n, int ksplit, int64_t stride) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += part[k * stride + i];
+    out[i] = s;
+}
+
+// Split-K form for long contractions over few output tiles (the dK / dV reductions over up to 4096 queries):
+// `ksplit` partial products go to `partial` (ksplit * c_elems floats), then a fixed-order reduction writes the dense
+// output C (c_elems floats, laid out by sc0/sc1/scm).  Deterministic, no atomics.
+int skp_gemm_nt_splitk(const float* A, const float* B, float* C, float* partial, int64_t c_elems, int ksplit,
+                       int M, int N, int K, int Z0, int Z1,
+                       int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
+                       int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
+                       int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream) {
+    if (ksplit <= 1 || !partial)
+        return gemm_launch(A, B, C, M, N, N, K, Z0, Z1, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha, stream);
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || Z0 <= 0 || Z1 <= 0) return SKP_E_BADARG;
+    if ((int64_t)Z0 * Z1 * ksplit > 65535) return SKP_E_RANGE;
+    const int kchunk = (((K + ksplit - 1) / ksplit) + 7) & ~7;
+    GemmArgs g{A, B, partial, M, N, K, Z1, N, ksplit, kchunk, c_elems, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
+    dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1 * ksplit);
+    hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    int rc = skp_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(skp_splitk_reduce_kernel, dim3((unsigned)((c_elems + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)partial, C, c_elems, ksplit, c_elems);
     return skp_launch_status();
 }
 

@@ -325,7 +325,7 @@ class CrossAttnFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dk = torch.empty(B, T, C, device=q.device, dtype=torch.float32)
         dv = torch.empty_like(dk)
-        nbytes = N.lib().skp_cross_attn_bwd_workspace(B, heads, Nq, T)
+        nbytes = N.lib().skp_cross_attn_bwd_workspace(B, heads, Nq, T, C // heads)
         ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
         N.check(N.lib().skp_cross_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                                lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(),
