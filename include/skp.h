@@ -15,6 +15,7 @@
  *   skp_attn_map_fwd_f32 / _bwd_f32         ptp_utils.py:513-538 + optimize.py:27-79
  *                                           (bicubic up-res softmax map, per-head store, layer/head mean)
  *   skp_cross_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (ordinary softmax(QK^T)V, cross layers)
+ *   skp_self_attn_fwd_f32 / _bwd_f32        ptp_utils.py:493-506,540 (self-attention layers, flash-style)
  *   skp_group_norm_fwd_f32 / _bwd_f32       GroupNorm+SiLU of the hooked UNet / VAE forward (ptp_utils.py:227-229, 289-304)
  *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
  *   skp_select_tokens                       ptp_utils.py:110-112,115-159
@@ -116,6 +117,16 @@ int skp_cross_attn_bwd_f32(const float* q, const float* k, const float* v, const
 int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/,
                             int L, int B, int H, int T, int R, const float* dM, const float* lse,
                             float* workspace, float* dot_io, int ldt, int64_t m_bstride, int mode, void* stream);
+
+/* Flash-style self-attention (ptp_utils.py:493-506 with context = x) for the long image-token sequences: fp32 MFMA,
+ * 64-key tiles in LDS, online softmax; the [B*h,N,N] scores are never materialised.
+ * q, k, v, out: [B,N,H*d]; lse: [B,H,N] (natural log).  Limits: d in {8,16,40,80,160}. */
+int skp_self_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
+                          int B, int H, int N, int d, float scale, void* stream);
+/* Backward: dq, dk, dv [B,N,H*d] written; workspace: B*H*N floats.  Deterministic (no atomics). */
+int skp_self_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                          const float* lse, float* dq, float* dk, float* dv, float* workspace,
+                          int B, int H, int N, int d, float scale, void* stream);
 
 /* Fused GroupNorm (+ per-(sample,channel) offset) (+ SiLU) of the frozen UNet/VAE blocks (diffusers ResnetBlock2D:
  * conv -> [+bias, + time embedding] -> GroupNorm -> SiLU), NCHW:

@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -66,8 +66,6 @@ def lib():
     l = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         if not hasattr(l, name):
-            if name.startswith("skp_self_attn"):
-                continue                       # optional until built (declared in skp.h only when present)
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}")
         fn = getattr(l, name)
         fn.argtypes = argtypes

@@ -14,9 +14,8 @@
 // dS = P (dP - rowsum(dO*O)), dQ = scale dS.K in-kernel; P and dS are staged token-major
 // ([B,H,TP,N], n contiguous, coalesced) for the two reductions over queries dK = scale dS^T.Q and
 // dV = P^T.dO, which run on skp_gemm_nt_f32.
-#include "skp_common.h"
+#include "skp_attn_tiles.h"
 
-#define SKP_LN2 0.6931471805599453f
 #define SKP_CA_KSPLIT_MAX 16
 
 int skp_gemm_nt_splitk(const float* A, const float* B, float* C, float* partial, int64_t c_elems, int ksplit,
@@ -26,65 +25,6 @@ int skp_gemm_nt_splitk(const float* A, const float* B, float* C, float* partial,
                        int64_t sc0, int64_t sc1, int64_t scm, float alpha, void* stream);
 
 static int ca_ksplit(int N) { int k = N / 256; return k < 1 ? 1 : (k > SKP_CA_KSPLIT_MAX ? SKP_CA_KSPLIT_MAX : k); }
-
-template <int D8, int TT>
-struct CAShape {
-    static constexpr int D = D8 * 8, LDK = D + 4, CT = (D + 31) / 32, TP = TT * 32;
-    static constexpr int LDS_FLOATS = TP * LDK + 64;
-};
-
-// token index of accumulator register r of t-tile tt for this lane half
-__device__ __forceinline__ int ca_tok(int tt, int r, int hi) { return tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; }
-
-template <int D8, int TT>
-__device__ __forceinline__ void ca_stage(float* smem, const float* __restrict__ src, int T, int C, int tid) {
-    using S = CAShape<D8, TT>;
-    constexpr int Q4 = S::D / 4;
-    for (int idx = tid; idx < S::TP * Q4; idx += 256) {
-        const int t = idx / Q4, c4 = idx - t * Q4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t < T) v = *(const f32x4*)(src + (size_t)t * C + c4 * 4);
-        *(f32x4*)(smem + t * S::LDK + c4 * 4) = v;
-    }
-}
-
-// acc[tt] (+)= X . Y^T with X rows from LDS (tokens) and Y rows in registers (this lane's query row)
-template <int D8, int TT>
-__device__ __forceinline__ void ca_swapped_product(const float* smem, const f32x4 (&yv)[D8], f32x16 (&acc)[TT],
-                                                   int i, int hi) {
-    using S = CAShape<D8, TT>;
-#pragma unroll
-    for (int j = 0; j < D8; ++j) {
-        f32x4 xa[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) xa[tt] = *(const f32x4*)(smem + (tt * 32 + i) * S::LDK + 8 * j + 4 * hi);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[tt][m], yv[j][m], acc[tt], 0, 0, 0);
-    }
-}
-
-// o[ct] = P . X   (P in registers as A operand; X rows (tokens) from LDS as B operand)
-template <int D8, int TT>
-__device__ __forceinline__ void ca_reg_product(const float* smem, const f32x16 (&p)[TT],
-                                               f32x16 (&o)[CAShape<D8, TT>::CT], int i, int hi) {
-    using S = CAShape<D8, TT>;
-#pragma unroll
-    for (int ct = 0; ct < S::CT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* row = smem + ca_tok(tt, r, hi) * S::LDK + i;
-#pragma unroll
-            for (int ct = 0; ct < S::CT; ++ct)
-                o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[tt][r], row[ct * 32], o[ct], 0, 0, 0);
-        }
-}
 
 template <int D8, int TT>
 __global__ __launch_bounds__(256) void skp_cross_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,

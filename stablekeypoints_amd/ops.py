@@ -386,3 +386,43 @@ class GroupNormSiLUFn(torch.autograd.Function):
 
 def group_norm_silu(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
     return GroupNormSiLUFn.apply(x, off, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)
+
+
+# ---------------------------------------------------------------------------------------------
+# flash-style self-attention (long image-token sequences)          ptp_utils.py:493-506,540
+# ---------------------------------------------------------------------------------------------
+def self_attn_supported(C: int, heads: int) -> bool:
+    return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """out = merge_heads(softmax(scale q k^T) v) for q, k, v [B,N,C]; scores never materialised."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads: int, scale: float):
+        q, k, v = _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
+        B, Nq, C = q.shape
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
+        N.check(N.lib().skp_self_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                              B, heads, Nq, C // heads, float(scale), _stream()), "skp_self_attn_fwd_f32")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.meta = (heads, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        heads, scale = ctx.meta
+        dout = _dev(dout, "dout")
+        B, Nq, C = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        ws = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
+        N.check(N.lib().skp_self_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                              lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(),
+                                              B, heads, Nq, C // heads, scale, _stream()), "skp_self_attn_bwd_f32")
+        return dq, dk, dv, None, None
+
+
+def self_attention(q, k, v, heads: int, scale: float):
+    return SelfAttnFn.apply(q, k, v, int(heads), float(scale))

@@ -88,10 +88,12 @@ MAX_STORED_SEQ = 32 ** 2       # ptp_utils.py:510
 
 def _attention_core(module, q, k, v, is_cross=False):
     """softmax(scale q k^T) v per head (ptp_utils.py:493-506) on [B,N,C]/[B,T,C] tensors.  Cross layers with
-    a short key axis run on the fused fp32-MFMA kernel (csrc/skp_cross_attn.hip); self-attention keeps the
-    library path of the frozen network."""
+    a short key axis run on the fused fp32-MFMA kernel (csrc/skp_cross_attn.hip); self-attention runs on the
+    flash-style kernels (csrc/skp_self_attn.hip).  Unsupported head sizes keep the plain formulation."""
     if is_cross and q.is_cuda and ops.cross_attn_supported(q.shape[-1], module.heads, k.shape[1]):
         return ops.cross_attention(q, k, v, module.heads, module.scale)
+    if (not is_cross) and q.is_cuda and ops.self_attn_supported(q.shape[-1], module.heads):
+        return ops.self_attention(q, k, v, module.heads, module.scale)
     qh = module.reshape_heads_to_batch_dim(q)
     kh = module.reshape_heads_to_batch_dim(k)
     vh = module.reshape_heads_to_batch_dim(v)

@@ -283,3 +283,23 @@ def test_fused_group_norm_silu_fwd_bwd(ops, N, C, G, H, W, silu, with_off):
     torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
     (y * w.cuda()).sum().backward()
     torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,N,H,d", [(2, 1024, 8, 80), (1, 4096, 8, 40), (2, 200, 4, 8), (1, 256, 8, 160), (3, 64, 2, 16),
+                                     (1, 130, 4, 40)])
+def test_flash_self_attention_fwd_bwd_vs_fp64(ops, B, N, H, d):
+    """Flash-style fp32-MFMA self-attention against the materialised reference formulation in fp64."""
+    g = torch.Generator().manual_seed(13)
+    C = H * d
+    q, k, v, w = (torch.randn(B, N, C, generator=g) for _ in range(4))
+    scale = d ** -0.5
+    qd, kd, vd = (x.double().requires_grad_(True) for x in (q, k, v))
+    qh, kh, vh = R.split_heads(qd, H), R.split_heads(kd, H), R.split_heads(vd, H)
+    ref = R.merge_heads(torch.matmul((torch.einsum("bid,bjd->bij", qh, kh) * scale).softmax(-1), vh), H)
+    (ref * w.double()).sum().backward()
+    qg, kg, vg = (x.cuda().requires_grad_(True) for x in (q, k, v))
+    out = ops.self_attention(qg, kg, vg, H, scale)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    (out * w.cuda()).sum().backward()
+    for a, b in ((qg, qd), (kg, kd), (vg, vd)):
+        torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=1e-3, atol=2e-5 * b.grad.abs().max().item())
