@@ -101,6 +101,35 @@ def map_kernel_roofline(ops, B, T, R, iters, device):
     return out, fwd_bytes, bwd_bytes, flops_equiv
 
 
+def self_attn_roofline(ops, B, iters, device):
+    """Flash self-attention at the 64^2 layers of the step (N=4096 tokens, 8 heads x d=40, B rows): algorithmic
+    FLOPs = 4*N^2*d per (row, head) forward (QK^T + PV), 2.5x that backward (5 products), against the fp32 MFMA peak."""
+    g = torch.Generator(device="cpu").manual_seed(1)
+    Nq, H, d = 4096, 8, 40
+    q, k, v, w = (torch.randn(B, Nq, H * d, generator=g).to(device) for _ in range(4))
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    out = {}
+    fwd = lambda: ops.self_attention(q, k, v, H, d ** -0.5)
+    for _ in range(2):
+        o = fwd()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        o = fwd()
+    e1.record(); torch.cuda.synchronize()
+    out["fwd"] = e0.elapsed_time(e1) / iters * 1e-3
+    o = fwd()
+    for _ in range(2):
+        torch.autograd.grad(o, (q, k, v), w, retain_graph=True)
+    e0.record()
+    for _ in range(iters):
+        torch.autograd.grad(o, (q, k, v), w, retain_graph=True)
+    e1.record(); torch.cuda.synchronize()
+    out["bwd"] = e0.elapsed_time(e1) / iters * 1e-3
+    flops_fwd = 4.0 * Nq * Nq * d * B * H
+    return out, flops_fwd, 2.5 * flops_fwd
+
+
 def cpu_baseline(ldm_cpu, args):
     """Oracle reference-order CPU step (oracle/cpu_path.py) on a bounded sample: ONE image (2 UNet+VAE
     forwards with materialised attention + backward + Adam) at --cpu-image-size, after one untimed warm-up
@@ -217,6 +246,7 @@ def main():
     if rank == 0:
         B = 2 * per_rank                                          # rows per fused-map launch (both views)
         kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev)
+        sa, sa_f, sa_b = self_attn_roofline(ops, B, max(3, a.kernel_iters // 6), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
         line = {
@@ -236,6 +266,12 @@ def main():
                          "bwd_launch_us": kt["bwd"] * 1e6, "bwd_achieved": bwd_bytes / kt["bwd"] / 1e9,
                          "reference_contraction_equiv_tflops": flops_equiv / kt["fwd"] / 1e12,
                          "f32_matrix_peak_tflops": F32_MATRIX_PEAK_TF},
+            "roofline_self_attn": {"kernel": "skp_self_attn_fwd_kernel<5,2> (flash self-attention, 64^2 layers)",
+                                   "bound": "mfma", "achieved": sa_f / sa["fwd"] / 1e12, "peak": F32_MATRIX_PEAK_TF,
+                                   "unit": "TFLOP/s", "frac": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
+                                   "traffic": None, "launch_us": sa["fwd"] * 1e6, "algorithmic_flops": sa_f,
+                                   "bwd_us": sa["bwd"] * 1e6, "bwd_achieved": sa_b / sa["bwd"] / 1e12,
+                                   "rows_per_launch": B, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
             "cpu_baseline": cpu_stats,
             "loss": float(last[0]), "build_s": t_build,
         }

@@ -278,7 +278,7 @@ extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float
     switch (d) {
         case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 1, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 2, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 5, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
+        case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 5, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 10, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         default: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 20, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
     }

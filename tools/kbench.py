@@ -55,6 +55,12 @@ def main():
     timed("select_tokens", lambda: ops.select_tokens(kl, amt[0], R, 25, 10))
     _, sel = ops.select_tokens(kl, amt[0], R, 25, 10)
     timed("fused_losses", lambda: ops.fused_losses(M[0], Mt, sel, am, [0.9, 0.1, 0.05, -0.1, 0.9, -0.02], 2.0, 1))
+    for (n, C) in ((4096, 320), (1024, 640)):
+        qq, kk, vv, ww = (torch.randn(B, n, C, generator=g).to(dev) for _ in range(4))
+        qq.requires_grad_(True); kk.requires_grad_(True); vv.requires_grad_(True)
+        timed(f"self_attn_fwd N={n} C={C}", lambda: ops.self_attention(qq, kk, vv, H, (C // H) ** -0.5))
+        oo = ops.self_attention(qq, kk, vv, H, (C // H) ** -0.5)
+        timed(f"self_attn_bwd N={n} C={C}", lambda: torch.autograd.grad(oo, (qq, kk, vv), ww, retain_graph=True))
     for (n, C) in ((4096, 320), (1024, 640), (256, 1280)):
         q = torch.randn(B, n, C, generator=g).to(dev); k = torch.randn(1, T, C, generator=g).to(dev); v = torch.randn(1, T, C, generator=g).to(dev)
         timed(f"cross_attn_fwd N={n} C={C}", lambda: ops.cross_attention(q, k, v, H, (C // H) ** -0.5))
