@@ -141,6 +141,10 @@ int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma,
                            const float* dy, const float* mean, const float* rstd, float* dx, float* workspace,
                            int N, int C, int G, int HW, float eps, int silu, void* stream);
 
+/* out[n,c,p] = a[n,c,p] + b[n,c,p] + bias[c]  (ResnetBlock2D tail: shortcut + conv2 + conv2.bias in one pass). HW % 4 == 0. */
+int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias, float* out, int N, int C, int HW,
+                              void* stream);
+
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects
  *                         (first index wins ties; radius 0.05*R masking between maxima)

@@ -233,3 +233,27 @@ extern "C" int skp_group_norm_bwd_f32(const float* x, const float* off, const fl
                        (const float*)workspace, dx);
     return skp_launch_status();
 }
+
+// out[n,c,p] = a[n,c,p] + b[n,c,p] + bias[c]   (ResnetBlock2D tail: shortcut + conv2(no bias) + conv2.bias in one pass
+// instead of a broadcast bias-add pass followed by a residual-add pass)
+__global__ __launch_bounds__(256) void skp_add_bias_residual_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int C, int hw4, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c = (int)((i / hw4) % C);
+        const f32x4 va = *(const f32x4*)(a + i * 4), vb = *(const f32x4*)(b + i * 4);
+        *(f32x4*)(out + i * 4) = va + vb + bias[c];
+    }
+}
+
+extern "C" int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias, float* out, int N, int C,
+                                         int HW, void* stream) {
+    if (!a || !b || !bias || !out || N <= 0 || C <= 0 || HW <= 0) return SKP_E_BADARG;
+    if (HW % 4) return SKP_E_RANGE;
+    const long total4 = (long)N * C * HW / 4;
+    long blocks = (total4 + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(skp_add_bias_residual_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, bias,
+                       out, C, HW / 4, total4);
+    return skp_launch_status();
+}

@@ -29,10 +29,10 @@ def _resnet_forward(m: ResnetBlock2D):
         if m.time_emb_proj is not None and temb is not None:
             off = off + m.time_emb_proj(F.silu(temb))
         h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
-        h = m.conv2(h)
         if m.conv_shortcut is not None:
             x = m.conv_shortcut(x)
-        return x + h
+        h = F.conv2d(h, m.conv2.weight, None, padding=1)                 # bias added together with the residual
+        return ops.add_bias_residual(x, h, m.conv2.bias)
     return forward
 
 

@@ -426,3 +426,24 @@ class SelfAttnFn(torch.autograd.Function):
 
 def self_attention(q, k, v, heads: int, scale: float):
     return SelfAttnFn.apply(q, k, v, int(heads), float(scale))
+
+
+class AddBiasResidualFn(torch.autograd.Function):
+    """out = a + b + bias[None,:,None,None] in one pass (bias frozen); gradients pass straight through."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias):
+        a, b = _dev(a, "a"), _dev(b, "b")
+        Nn, C, Hh, Ww = a.shape
+        out = torch.empty_like(a)
+        N.check(N.lib().skp_add_bias_residual_f32(a.data_ptr(), b.data_ptr(), bias.data_ptr(), out.data_ptr(), Nn, C,
+                                                  Hh * Ww, _stream()), "skp_add_bias_residual_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy, None
+
+
+def add_bias_residual(a, b, bias):
+    return AddBiasResidualFn.apply(a, b, bias)
