@@ -72,12 +72,16 @@ def map_kernel_roofline(ops, B, T, R, iters, device):
     dp, k2 = N.ptr_array([t.data_ptr() for t in dS])
     si, k3 = N.int_array(sides)
     st = torch.cuda.current_stream().cuda_stream
-    ws = torch.empty(N.lib().skp_attn_map_bwd_workspace(si, 4, B, H, T, R) // 4, device=device)
+    ws = torch.empty(max(4, N.lib().skp_attn_map_bwd_workspace(si, 4, B, H, min(T, 128), R)) // 4, device=device)
 
     def run_fwd():
+        if T > 128:                                              # token-group path (several launches)
+            return ops._map_fwd(S, sides, B, H, T, R)
         N.check(N.lib().skp_attn_map_fwd_f32(sp, si, 4, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "fwd")
 
     def run_bwd():
+        if T > 128:
+            return ops._map_bwd(S, dS, sides, B, H, T, R, dM, lse)
         N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, 4, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "bwd")
 
     out = {}

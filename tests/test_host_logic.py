@@ -157,3 +157,28 @@ def test_optimize_embedding_rejects_bad_batch():
         optimize_embedding(None, default_args(batch_size=0), {torch.device("cpu"): AttentionStore()}, 1)
     a = default_args()
     assert a.num_tokens == 500 and a.feature_upsample_res == 128 and a.top_k == 10 and a.lr == 5e-3
+
+
+def test_c_abi_rejects_bad_arguments_before_launching():
+    """Every entry point validates pointers/sizes on the host and returns SKP_E_* (< 0) without touching the GPU."""
+    import ctypes as C
+    from stablekeypoints_amd import _native as N
+    lib = N.lib()
+    null = None
+    assert lib.skp_qk_logits_f32(null, null, null, 1, 1, 8, 77, 256, 160, 0.1, null) == -1
+    assert lib.skp_gemm_nt_f32(null, null, null, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, null) == -1
+    one = C.c_float(0.0)
+    p = C.cast(C.pointer(one), C.c_void_p)
+    sp, _k = N.ptr_array([p.value]); si, _k2 = N.int_array([16])
+    assert lib.skp_attn_map_fwd_f32(sp, si, 1, 1, 8, 500, 128, p, p, null) == -2          # T > 128: use the _ex form
+    assert lib.skp_attn_map_fwd_f32(sp, si, 9, 1, 8, 77, 128, p, p, null) == -2           # too many layers
+    assert lib.skp_attn_map_fwd_ex_f32(sp, si, 1, 1, 8, 77, 128, p, p, null, 64, 0, 0, null) == -1   # ldt < NT
+    assert lib.skp_attn_map_bwd_workspace(si, 0, 1, 8, 77, 128) < 0
+    assert lib.skp_attn_map_bwd_workspace(si, 1, 2, 8, 77, 128) == 2 * 8 * 128 * 16 * 80 * 4
+    assert lib.skp_cross_attn_fwd_f32(p, p, p, p, p, 1, 1, 8, 64, 77, 48, 0.1, null) == -2    # unsupported head dim
+    assert lib.skp_cross_attn_fwd_f32(p, p, p, p, p, 2, 3, 8, 64, 77, 40, 0.1, null) == -1    # Bk not in {1,B}
+    assert lib.skp_self_attn_fwd_f32(p, p, p, p, p, 1, 8, 64, 24, 0.1, null) == -2
+    assert lib.skp_group_norm_fwd_f32(p, null, p, p, p, p, p, p, 1, 30, 32, 16, 1e-5, 1, null) == -2   # C % G
+    assert lib.skp_select_tokens(p, p, 77, 128, 25, 1, p, p, null) == -2                  # top_k < 2
+    assert lib.skp_token_stats_f32(p, 77, 128, 9, 2.0, 1e-5, p, null, null) == -2          # too many subjects
+    assert lib.skp_losses_fwd_f32(p, p, p, 10, 77, 128, p, 1, 2.0, None, p, p, p, p, null) == -1
