@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) acc[pb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int lh = 0;
     for (int l = 0; l < a.L; ++l) {
         const int s = a.s[l];
@@ -416,14 +417,16 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
             __syncthreads();
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
+                // operands first (independent LDS reads), then the two k-steps over all t-tiles (no dependent pairs
+                // back to back), accumulating from a shared zero vector (no per-tile zero fills)
+                float a0[TT], a1[TT];
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) { a0[tt] = Vt[arow[pb][0] + 16 * tt]; a1[tt] = Vt[arow[pb][1] + 16 * tt]; }
                 f32x4 sv[TT];
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
-                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[arow[pb][0] + 16 * tt], wB[pb][0], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(Vt[arow[pb][1] + 16 * tt], wB[pb][1], d, 0, 0, 0);
-                    sv[tt] = d;
-                }
+                for (int tt = 0; tt < TT; ++tt) sv[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], wB[pb][0], zero4, 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) sv[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], wB[pb][1], sv[tt], 0, 0, 0);
                 if (TT * 16 > T) {                              // pads live in the last t-tile only
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -433,9 +436,11 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
                 if (MODE == 2) {
                     const float lse = pv[pb] ? lse_in[lidx] : 0.f;
 #pragma unroll
-                    for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[pb][tt][r] += __builtin_amdgcn_exp2f(sv[tt][r] - lse);
+                    for (int tt = 0; tt < TT; ++tt) {
+                        const f32x4 e = sv[tt] - lse;
+                        acc[pb][tt] += f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]),
+                                             __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
+                    }
                     continue;
                 }
                 float m = -INFINITY;
@@ -446,9 +451,10 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
                 f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[tt][r] = __builtin_amdgcn_exp2f(sv[tt][r] - m);
+                for (int tt = 0; tt < TT; ++tt) {               // vector ops on f32x4 lower to v_pk_add/v_pk_fma pairs
+                    const f32x4 e = sv[tt] - m;
+                    sv[tt] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]),
+                                   __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
                     s4 += sv[tt];
                 }
                 float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
                 if (MODE == 0) {
                     const float inv = 1.0f / sum;
 #pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) acc[pb][tt] += sv[tt] * inv;
+                    for (int tt = 0; tt < TT; ++tt) acc[pb][tt] = sv[tt] * inv + acc[pb][tt];
                 }
                 if (pv[pb] && g == 0) lse_out[lidx] = m + __builtin_amdgcn_logf(sum);
             }

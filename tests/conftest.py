@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def native_library_built():
+    """A fresh checkout has no libskp_hip.so (built artefacts are git-ignored): build it once per session
+    (hipcc cross-compiles gfx950 without a GPU)."""
+    lib = os.path.join(ROOT, "stablekeypoints_amd", "csrc", "libskp_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.dirname(lib), "-j8"], check=True)
+    return lib
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
