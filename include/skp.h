@@ -99,7 +99,7 @@ int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[h
  * LDS, softmax over the tokens in registers:
  *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]
  * q, out: [B,N,H*d]; k, v: [Bk,T,H*d] with Bk in {1,B}; lse: [B,H,N] natural-log sum-exp (for _bwd).
- * Limits: T <= 128, d in {8,16,40,80,160}. */
+ * Limits: T <= 128, d in {8,16,32,40,64,80,160}. */
 int skp_cross_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
                            int B, int Bk, int H, int N, int T, int d, float scale, void* stream);
 /* Scratch bytes of skp_cross_attn_bwd_f32 (token-major staging of P and dS); negative on bad arguments. */
@@ -120,7 +120,7 @@ int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /
 
 /* Flash-style self-attention (ptp_utils.py:493-506 with context = x) for the long image-token sequences: fp32 MFMA,
  * 64-key tiles in LDS, online softmax; the [B*h,N,N] scores are never materialised.
- * q, k, v, out: [B,N,H*d]; lse: [B,H,N] (natural log).  Limits: d in {8,16,40,80,160}. */
+ * q, k, v, out: [B,N,H*d]; lse: [B,H,N] (natural log).  Limits: d in {8,16,32,40,64,80,160}. */
 int skp_self_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
                           int B, int H, int N, int d, float scale, void* stream);
 /* Backward: dq, dk, dv [B,N,H*d] written; workspace: B*H*N floats.  Deterministic (no atomics). */

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void skp_cross_attn_bwd_kernel(const float* __
 static int ca_check(int B, int Bk, int H, int N, int T, int d) {
     if (B <= 0 || H <= 0 || N <= 0 || T <= 0 || d <= 0 || (Bk != 1 && Bk != B)) return SKP_E_BADARG;
     if (T > 128 || B > 65535 || H > 65535) return SKP_E_RANGE;
-    if (d != 8 && d != 16 && d != 40 && d != 80 && d != 160) return SKP_E_RANGE;
+    if (d != 8 && d != 16 && d != 32 && d != 40 && d != 64 && d != 80 && d != 160) return SKP_E_RANGE;
     return 0;
 }
 
@@ -190,7 +190,9 @@ static int ca_check(int B, int Bk, int H, int N, int T, int d) {
         int launched = 0;                                                                                \
         SKP_CA_CASE(KERNEL, 1, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 1, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 1, 4, __VA_ARGS__)     \
         SKP_CA_CASE(KERNEL, 2, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 2, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 2, 4, __VA_ARGS__)     \
+        SKP_CA_CASE(KERNEL, 4, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 4, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 4, 4, __VA_ARGS__)     \
         SKP_CA_CASE(KERNEL, 5, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 5, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 5, 4, __VA_ARGS__)     \
+        SKP_CA_CASE(KERNEL, 8, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 8, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 8, 4, __VA_ARGS__)     \
         SKP_CA_CASE(KERNEL, 10, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 10, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 10, 4, __VA_ARGS__)  \
         SKP_CA_CASE(KERNEL, 20, 1, __VA_ARGS__) SKP_CA_CASE(KERNEL, 20, 3, __VA_ARGS__) SKP_CA_CASE(KERNEL, 20, 4, __VA_ARGS__)  \
         if (!launched) return SKP_E_RANGE;                                                               \

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dkv_kernel(const float*
 static int sa_check(int B, int H, int N, int d) {
     if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return SKP_E_BADARG;
     if (B > 65535 || H > 65535) return SKP_E_RANGE;
-    if (d != 8 && d != 16 && d != 40 && d != 80 && d != 160) return SKP_E_RANGE;
+    if (d != 8 && d != 16 && d != 32 && d != 40 && d != 64 && d != 80 && d != 160) return SKP_E_RANGE;
     return 0;
 }
 
@@ -250,7 +250,9 @@ extern "C" int skp_self_attn_fwd_f32(const float* q, const float* k, const float
     switch (d) {
         case 8: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 1, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
         case 16: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 2, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
+        case 32: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 4, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
         case 40: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 5, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
+        case 64: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 8, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
         case 80: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 10, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
         default: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 20, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
     }
@@ -269,7 +271,9 @@ extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float
     switch (d) {
         case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 1, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
         case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 2, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
+        case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 4, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
         case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 5, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
+        case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 8, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
         case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 10, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
         default: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 20, 1, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
     }
@@ -278,7 +282,9 @@ extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float
     switch (d) {
         case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 1, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 2, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
+        case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 4, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 5, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
+        case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 8, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 10, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
         default: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 20, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
     }

@@ -290,7 +290,7 @@ def fused_losses(M, Mt, sel, argmax, theta, sigma: float, num_subjects: int = 1)
 # ---------------------------------------------------------------------------------------------
 # ordinary cross-attention core (short key axis)                 ptp_utils.py:493-506,540
 # ---------------------------------------------------------------------------------------------
-CROSS_ATTN_HEAD_DIMS = (8, 16, 40, 80, 160)
+CROSS_ATTN_HEAD_DIMS = (8, 16, 32, 40, 64, 80, 160)
 CROSS_ATTN_MAX_T = 128
 
 

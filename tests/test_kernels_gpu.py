@@ -205,7 +205,8 @@ def test_sd_shape_maps_invariants(ops):
 
 
 @pytest.mark.parametrize("B,Bk,N,H,d,T", [(2, 1, 256, 8, 160, 77), (1, 1, 100, 4, 8, 16), (2, 2, 1024, 8, 80, 77),
-                                          (1, 1, 4096, 8, 40, 100), (3, 1, 64, 2, 16, 5)])
+                                          (1, 1, 4096, 8, 40, 100), (3, 1, 64, 2, 16, 5), (1, 1, 576, 5, 64, 77),
+                                          (2, 1, 96, 3, 32, 30)])
 def test_cross_attention_fwd_bwd_vs_fp64(ops, B, Bk, N, H, d, T):
     """Fused fp32-MFMA cross-attention (ptp_utils.py:493-506) against the reference formulation in fp64."""
     g = torch.Generator().manual_seed(11)
@@ -286,7 +287,7 @@ def test_fused_group_norm_silu_fwd_bwd(ops, N, C, G, H, W, silu, with_off):
 
 
 @pytest.mark.parametrize("B,N,H,d", [(2, 1024, 8, 80), (1, 4096, 8, 40), (2, 200, 4, 8), (1, 256, 8, 160), (3, 64, 2, 16),
-                                     (1, 130, 4, 40)])
+                                     (1, 130, 4, 40), (1, 576, 5, 64), (2, 100, 2, 32)])
 def test_flash_self_attention_fwd_bwd_vs_fp64(ops, B, N, H, d):
     """Flash-style fp32-MFMA self-attention against the materialised reference formulation in fp64."""
     g = torch.Generator().manual_seed(13)
