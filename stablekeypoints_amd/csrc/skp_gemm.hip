@@ -1,8 +1,7 @@
 // Batched NT GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32): exact fp32 fma chain,
 // 157 TF/s peak on MI355X.  Replaces the q.k^T contractions of ptp_utils.py:493,534 and their
 // backward products.  One wave owns one 32x32 output tile; operands are read straight from
-// global/L2 (the matrices of this path are <= a few MB and L2 resident), K is walked 2 at a
-// time: lane l supplies A[m0 + (l&31)][k0 + (l>>5)] and B[n0 + (l&31)][k0 + (l>>5)].
+// global/L2 (the matrices of this path are <= a few MB and L2 resident).
 #include "skp_common.h"
 
 struct GemmArgs {
@@ -17,6 +16,9 @@ struct GemmArgs {
     float alpha;
 };
 
+// K is walked 8 at a time; lane l supplies k = k0 + 4*(l>>5) + m for MFMA m = 0..3, so an operand whose k
+// axis is contiguous (sXk == 1) is fetched with ONE float4 load per lane per 4 MFMAs.
+template <bool AV, bool BV>
 __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, hi = lane >> 5;
@@ -26,27 +28,27 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     const int zz = blockIdx.z / g.ksplit, ks = blockIdx.z - zz * g.ksplit;
     const int z0 = zz / g.Z1, z1 = zz - z0 * g.Z1;
     const bool mv = (m0 + i) < g.M, nv = (n0 + i) < g.Nload, ns = (n0 + i) < g.N;
-    const float* Ap = g.A + z0 * g.sa0 + z1 * g.sa1 + (int64_t)(mv ? m0 + i : 0) * g.sam + hi * g.sak;
-    const float* Bp = g.B + z0 * g.sb0 + z1 * g.sb1 + (int64_t)(nv ? n0 + i : 0) * g.sbn + hi * g.sbk;
+    const float* Ap = g.A + z0 * g.sa0 + z1 * g.sa1 + (int64_t)(mv ? m0 + i : 0) * g.sam;
+    const float* Bp = g.B + z0 * g.sb0 + z1 * g.sb1 + (int64_t)(nv ? n0 + i : 0) * g.sbn;
     f32x16 acc = {0};
     const int kbeg = ks * g.kchunk;
     const int K = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;     // kchunk is a multiple of 8
     int k = kbeg;
-    for (; k + 8 <= K; k += 8) {                               // 4 MFMAs per trip, loads issued first
-        float a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = Ap[(int64_t)(k + 2 * u) * g.sak];
-            b[u] = Bp[(int64_t)(k + 2 * u) * g.sbk];
-        }
+    for (; k + 8 <= K; k += 8) {
+        const int kk = k + 4 * hi;
+        f32x4 a, b;
+        if (AV) a = *(const f32x4*)(Ap + kk);
+        else { a[0] = Ap[(int64_t)kk * g.sak]; a[1] = Ap[(int64_t)(kk + 1) * g.sak]; a[2] = Ap[(int64_t)(kk + 2) * g.sak]; a[3] = Ap[(int64_t)(kk + 3) * g.sak]; }
+        if (BV) b = *(const f32x4*)(Bp + kk);
+        else { b[0] = Bp[(int64_t)kk * g.sbk]; b[1] = Bp[(int64_t)(kk + 1) * g.sbk]; b[2] = Bp[(int64_t)(kk + 2) * g.sbk]; b[3] = Bp[(int64_t)(kk + 3) * g.sbk]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mv ? a[u] : 0.f, nv ? b[u] : 0.f, acc, 0, 0, 0);
     }
-    for (; k < K; k += 2) {
+    for (; k < K; k += 2) {                                    // tail: k-slot = k + hi
         const bool kv = (k + hi) < K;
-        const float a = (kv && mv) ? Ap[(int64_t)k * g.sak] : 0.f;
-        const float b = (kv && nv) ? Bp[(int64_t)k * g.sbk] : 0.f;
+        const float a = (kv && mv) ? Ap[(int64_t)(k + hi) * g.sak] : 0.f;
+        const float b = (kv && nv) ? Bp[(int64_t)(k + hi) * g.sbk] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
@@ -60,6 +62,19 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+static void gemm_dispatch(const GemmArgs& g, dim3 grid, hipStream_t st) {
+    // float4 path needs a unit k stride and 16-byte aligned rows (base pointer, row and batch strides multiples of 4)
+    auto vec_ok = [](const float* p, int64_t s0, int64_t s1, int64_t sr, int64_t sk) {
+        return sk == 1 && ((uintptr_t)p & 15) == 0 && (s0 & 3) == 0 && (s1 & 3) == 0 && (sr & 3) == 0;
+    };
+    const bool av = vec_ok(g.A, g.sa0, g.sa1, g.sam, g.sak) && (g.kchunk % 8 == 0);
+    const bool bv = vec_ok(g.B, g.sb0, g.sb1, g.sbn, g.sbk) && (g.kchunk % 8 == 0);
+    if (av && bv) hipLaunchKernelGGL((skp_gemm_nt_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (av) hipLaunchKernelGGL((skp_gemm_nt_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (bv) hipLaunchKernelGGL((skp_gemm_nt_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((skp_gemm_nt_kernel<false, false>), grid, dim3(256), 0, st, g);
+}
+
 static int gemm_launch(const float* A, const float* B, float* C, int M, int N, int Nload, int K, int Z0, int Z1,
                        int64_t sa0, int64_t sa1, int64_t sam, int64_t sak,
                        int64_t sb0, int64_t sb1, int64_t sbn, int64_t sbk,
@@ -68,7 +83,7 @@ static int gemm_launch(const float* A, const float* B, float* C, int M, int N, i
     if ((int64_t)Z0 * Z1 > 65535) return SKP_E_RANGE;
     GemmArgs g{A, B, C, M, N, K, Z1, Nload, 1, (K + 7) & ~7, 0, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
     dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1);
-    hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    gemm_dispatch(g, grid, (hipStream_t)stream);
     return skp_launch_status();
 }
 
@@ -97,7 +112,7 @@ int skp_gemm_nt_splitk(const float* A, const float* B, float* C, float* partial,
     const int kchunk = (((K + ksplit - 1) / ksplit) + 7) & ~7;
     GemmArgs g{A, B, partial, M, N, K, Z1, N, ksplit, kchunk, c_elems, sa0, sa1, sam, sak, sb0, sb1, sbn, sbk, sc0, sc1, scm, alpha};
     dim3 grid((N + 63) / 64, (M + 63) / 64, Z0 * Z1 * ksplit);
-    hipLaunchKernelGGL(skp_gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    gemm_dispatch(g, grid, (hipStream_t)stream);
     int rc = skp_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(skp_splitk_reduce_kernel, dim3((unsigned)((c_elems + 255) / 256)), dim3(256), 0,
