@@ -546,16 +546,30 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
             const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
             const float lse = tl.valid ? lse_in[li] : 0.f;
             float sv[NT];
-            float dot = 0.f;
+            f32x4 dot4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float v = wx[0] * Vt[base[0] + t];
-                v = fmaf(wx[1], Vt[base[1] + t], v);
-                v = fmaf(wx[2], Vt[base[2] + t], v);
-                v = fmaf(wx[3], Vt[base[3] + t], v);
-                sv[t] = (t < T) ? __builtin_amdgcn_exp2f(v - lse) : 0.f;
-                dot = fmaf(sv[t], g[t], dot);
+            for (int q = 0; q < NT / 4; ++q) {                  // token quads: ds_read_b128 per tap, packed fp32 math
+                const f32x4 t0 = *(const f32x4*)(Vt + base[0] + 4 * q);
+                const f32x4 t1 = *(const f32x4*)(Vt + base[1] + 4 * q);
+                const f32x4 t2 = *(const f32x4*)(Vt + base[2] + 4 * q);
+                const f32x4 t3 = *(const f32x4*)(Vt + base[3] + 4 * q);
+                f32x4 v = wx[0] * t0;
+                v = wx[1] * t1 + v;
+                v = wx[2] * t2 + v;
+                v = wx[3] * t3 + v;
+                v = v - lse;
+                f32x4 pr = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1]), __builtin_amdgcn_exp2f(v[2]),
+                            __builtin_amdgcn_exp2f(v[3])};
+                if (4 * q >= NT - 16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * q + e >= T) pr[e] = 0.f;
+                }
+                const f32x4 g4 = {g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+                dot4 += pr * g4;
+                sv[4 * q] = pr[0]; sv[4 * q + 1] = pr[1]; sv[4 * q + 2] = pr[2]; sv[4 * q + 3] = pr[3];
             }
+            float dot = (dot4[0] + dot4[1]) + (dot4[2] + dot4[3]);
             if (MODE == 1) { if (tl.valid) dot_io[li] = dot; continue; }   // statistics pass of a token group
             if (MODE == 2) dot = tl.valid ? dot_io[li] : 0.f;               // sum over ALL token groups
             float* dVg = dV + (size_t)b * a.dv_per_b + a.dv_off[l] +
