@@ -176,6 +176,8 @@ def main():
     world, rank, local = D.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    if os.environ.get("SKP_BENCH_SINGLE_DEVICE") == "1":       # test hook: several ranks share cuda:0 (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # host threads: N ranks share the box's cores (weight init + the Python driver are the only CPU work)

@@ -165,3 +165,21 @@ def test_find_best_indices_runs():
     idx = find_best_indices(ldm, torch.randn(1, 16, 768, generator=torch.Generator().manual_seed(2)).cuda(), args,
                             controllers, n)
     assert idx.shape == (4,) and idx.dtype == torch.int64 and len(set(idx.tolist())) == 4 and idx.max() < 16
+
+
+def test_bench_two_ranks_one_gpu_gloo():
+    """bench.py through torch.distributed.run with WORLD_SIZE=2 (both ranks on cuda:0, gloo instead of RCCL):
+    barrier / max-over-ranks timing / gradient all-reduce / single JSON line from rank 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SKP_DIST_BACKEND="gloo", SKP_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--model", "tiny",
+           "--image-size", "128", "--res", "32", "--tokens", "16", "--steps", "2", "--warmup", "1", "--cpu-baseline", "off",
+           "--kernel-iters", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["scaling"] == "weak" and d["steps"] == 2
