@@ -261,6 +261,53 @@ def test_many_tokens_grouped_path_matches_fp64(ops):
         torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=2e-3, atol=2e-5 * b.grad.abs().max().item())
 
 
+def _ref_maps_fp64(qd, kd, layers, heads, scales, Rr, B):
+    """Reference order of operations (ptp_utils.py:513-538 + optimize.py:27-79) in fp64: upsample the
+    layer input's queries, per-head softmax over tokens, mean over layers and heads -> [B,T,R,R]."""
+    maps = []
+    for q, k, (sl, Cl), sc in zip(qd, kd, layers, scales):
+        T = k.shape[1]
+        qi = q.reshape(B, sl, sl, Cl).permute(0, 3, 1, 2)
+        qu = torch.nn.functional.interpolate(qi, size=(Rr, Rr), mode="bicubic", align_corners=False)
+        qu = R.split_heads(qu.permute(0, 2, 3, 1).reshape(B, Rr * Rr, Cl), heads)
+        kk = R.split_heads(k.expand(B, -1, -1), heads)
+        p = (torch.einsum("bid,bjd->bij", qu, kk) * sc).softmax(-1)
+        maps.append(p.reshape(B, heads, Rr, Rr, T).permute(0, 1, 4, 2, 3))
+    return torch.stack(maps, 0).mean(dim=(0, 2))
+
+
+@pytest.mark.parametrize("name,layers,heads,T,Rr", [
+    # BASELINE configs[3]: SD-2.1 at 768^2 -> latents 96^2; the hooked "up" cross layers with seq <= 32^2 are
+    # the three 24^2 layers of up_blocks.1 (C=1280, 20 heads of 64); fractional bicubic ratio on purpose
+    ("sd21_768", [(24, 1280)] * 3, 20, 77, 100),
+    # BASELINE configs[0]: SD-1.5 at 256^2 -> latents 32^2: 8^2 x3 (C=1280) + 16^2 (C=1280), 8 heads
+    ("sd15_256", [(8, 1280)] * 3 + [(16, 1280)], 8, 77, 64),
+    # BASELINE configs[4]: SDXL at 1024^2 -> latents 128^2; hooked layers are 32^2, C=1280, 20 heads of 64
+    # (two of the four layers, to keep the fp64 CPU side at a few seconds)
+    ("sdxl_1024", [(32, 1280)] * 2, 20, 77, 128),
+])
+def test_other_baseline_config_shapes_vs_fp64(ops, name, layers, heads, T, Rr):
+    """The attention-map path at the shapes of the other BASELINE configs (parity-test cases, not bench
+    lines): forward map rtol 1e-3 and the q/k gradients against fp64 autograd of the reference order."""
+    B = 2
+    g = torch.Generator().manual_seed(17)
+    qs = [torch.randn(B, sl * sl, Cl, generator=g) for sl, Cl in layers]
+    ks = [torch.randn(1, T, Cl, generator=g) for sl, Cl in layers]
+    W = torch.randn(B, T, Rr, Rr, generator=g)
+    scales = [(Cl // heads) ** -0.5 for _, Cl in layers]
+    qd = [q.double().requires_grad_(True) for q in qs]
+    kd = [k.double().requires_grad_(True) for k in ks]
+    Mref = _ref_maps_fp64(qd, kd, layers, heads, scales, Rr, B)
+    (Mref * W.double()).sum().backward()
+    qg = [q.cuda().requires_grad_(True) for q in qs]
+    kg = [k.cuda().requires_grad_(True) for k in ks]
+    M = ops.attn_map(qg, kg, heads, scales, Rr)
+    torch.testing.assert_close(M.detach().cpu().double(), Mref.detach(), rtol=1e-3, atol=1e-6)
+    (M * W.cuda()).sum().backward()
+    for a, b in zip(qg + kg, qd + kd):
+        torch.testing.assert_close(a.grad.cpu().double(), b.grad, rtol=2e-3, atol=2e-5 * b.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("N,C,G,H,W,silu,with_off", [(2, 64, 32, 16, 16, True, True), (8, 320, 32, 64, 64, True, True),
                                                       (1, 128, 32, 40, 24, False, False), (3, 32, 32, 6, 6, True, False),
                                                       (2, 512, 32, 128, 128, True, False)])
