@@ -145,6 +145,19 @@ int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma,
 int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias, float* out, int N, int C, int HW,
                               void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution of the frozen blocks (diffusers ResnetBlock2D.conv1/conv2, Upsample2D.conv,
+ * AutoencoderKL encoder resnets [third party], reached from ptp_utils.py:213-217 and :287) as Winograd F(2x2,3x3)
+ * on the fp32 matrix cores.
+ * skp_conv3x3_filter_f32: one-off transform of a frozen weight w [Cout,Cin,3,3] into the kernel's operand order
+ *   U [16][Cin/8][2][Cout][4] (16*Cin*Cout floats; Cin % 8 == 0).  flip_transpose = 1 builds the filter of the
+ *   backward-data convolution instead: pass the SAME w [Cw_out,Cw_in,3,3] with Cout = Cw_in, Cin = Cw_out.
+ * skp_conv3x3_f32: y [B,Cout,H,W] = conv(x [B,Cin,H,W]) (+ bias[Cout] if non-NULL).  Cout % 32 == 0;
+ *   variant 0 = auto, 1 = workgroup of 128 channels x 32 tiles (Cin % 32 == 0), 2 = 64 channels x 64 tiles
+ *   (Cin % 16 == 0).  x and U must each be < 2 GiB (32-bit buffer offsets), else SKP_E_RANGE. */
+int skp_conv3x3_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream);
+int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
+                    int variant, void* stream);
+
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects
  *                         (first index wins ties; radius 0.05*R masking between maxima)

@@ -1,0 +1,313 @@
+// 3x3 / stride 1 / pad 1 convolution of the frozen UNet + VAE blocks as Winograd F(2x2,3x3) on the fp32
+// matrix cores.  (The reference runs these through nn.Conv2d of diffusers' ResnetBlock2D / Upsample2D /
+// AutoencoderKL encoder [third party]; they are ~64 % of the optimisation step.)
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, summed over input channels
+//
+// The 16 element-wise products over channels are 16 independent GEMMs  M_p[co][tile] = U_p[co][ci] V_p[ci][tile],
+// i.e. 2.25x fewer multiplies than the direct form, all of them on v_mfma_f32_32x32x2_f32.
+//
+// Work split: a wave owns 32 output channels x 32 tiles x all 16 Winograd positions = 16 accumulator tiles
+// (256 accumulator registers: one wave per SIMD, 512-register budget), so the output transform A^T M A is
+// purely in-lane and nothing but the final activations goes back to HBM.  The workgroup (4 waves = CB
+// channel blocks x TB tile blocks) transforms its input patches once per channel chunk into LDS
+// (double buffered, 2 x 64 KB), already in MFMA operand order; the filter side U is transformed once per
+// layer (weights are frozen) into the same operand order and streamed from L2 with 512-byte coalesced
+// b128 loads.  Tiles sit on the lane axis, so the 2x2 outputs leave as coalesced float2 rows.
+#include "skp_common.h"
+
+namespace {
+
+// Raw buffer loads: wave-uniform base in SGPRs, 32-bit per-lane byte offset, scalar offset for the channel step;
+// an offset with bit 31 set is out of range for the descriptor and returns 0 (used for the zero padding).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ float skp_buf_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x4 skp_buf_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ i32x4 skp_make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));      // stride 0
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+#define SKP_OOB ((int)0x80000000)
+
+// ---- filter transform: U'[p][ci/8][(ci%8)/4][co][ci%4] = (G g G^T)[p]  ------------------------------------
+// flip_t = 0: g = w[co][ci]            (forward)
+// flip_t = 1: g = rot180(w[ci][co])    (backward-data: a convolution with Cin and Cout swapped)
+__global__ void skp_wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int flip_t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    float g[3][3];
+    if (!flip_t) {
+        const float* p = w + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p[a * 3 + b];
+    } else {
+        const float* p = w + ((size_t)ci * Cout + co) * 9;      // w is [Cin_of_this_conv = original Cout][...]
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p[(2 - a) * 3 + (2 - b)];
+    }
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int c8 = ci >> 3, kh = (ci >> 2) & 1, m = ci & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float u[4];
+        u[0] = t[i][0];
+        u[1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+        u[2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+        u[3] = t[i][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = i * 4 + j;
+            U[((((size_t)p * (Cin >> 3) + c8) * 2 + kh) * Cout + co) * 4 + m] = u[j];
+        }
+    }
+}
+
+struct WinoArgs {
+    const float* x;
+    const float* U;
+    const float* bias;      // may be null
+    float* y;
+    int B, Cin, Cout, H, W;
+    int tilesX, tilesPerImg, nTiles;
+    unsigned x_bytes, u_bytes;
+};
+
+template <int CB, int TB>
+struct WinoShape {
+    static constexpr int NTILE = 32 * TB;           // tiles per workgroup
+    static constexpr int KC = 1024 / NTILE;         // input channels per stage (one patch quad per thread)
+    static constexpr int NC8 = KC / 8;
+    static constexpr int STAGE_F4 = 16 * NC8 * 2 * NTILE;   // float4 per stage (= 4096 -> 64 KB)
+};
+
+// one thread: the 4x4 patches of 4 consecutive channels of one tile -> B^T d B -> 16 float4 into LDS
+struct PatchIdx {
+    int off[4][4];          // byte offset of (row i, col j) of channel quad 0 of this tile's image, or SKP_OOB
+};
+
+template <int CB, int TB>
+__global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
+    using S = WinoShape<CB, TB>;
+    extern __shared__ f32x4 vst[];                   // [2][16][NC8][2][NTILE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int cbi = wave % CB, tbi = wave / CB;
+    const int tile0 = blockIdx.x * S::NTILE;
+    const int n0 = (blockIdx.y * CB + cbi) * 32;
+    const bool wave_active = n0 < a.Cout;
+    const int HW = a.H * a.W;
+
+    // ---- this thread's patch (transform role) ----
+    const int tl = tid % S::NTILE, qd = tid / S::NTILE;         // tile in WG, channel quad in stage
+    PatchIdx pi;
+    {
+        const int tg = tile0 + tl;
+        const bool tv = tg < a.nTiles;
+        const int tgc = tv ? tg : 0;
+        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        const int base = (b * a.Cin + 4 * qd) * HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 2 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 2 * tx - 1 + j;
+                const bool ok = tv && r >= 0 && r < a.H && c >= 0 && c < a.W;
+                pi.off[i][j] = ok ? (base + r * a.W + c) * 4 : SKP_OOB;
+            }
+        }
+    }
+    const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
+    const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
+    float d[4][4][4];                                           // [m][row][col]
+    auto load_patch = [&](int cin0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int so = (cin0 + m) * HW * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[m][i][j] = skp_buf_load_f32(xrs, pi.off[i][j], so, 0);
+        }
+    };
+    auto transform_store = [&](int buf) {
+        f32x4* dst = vst + buf * S::STAGE_F4 + (size_t)qd * S::NTILE + tl;   // (c8*2+kh) == qd
+        float v[4][16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[m][0][j] - d[m][2][j];
+                t[1][j] = d[m][1][j] + d[m][2][j];
+                t[2][j] = d[m][2][j] - d[m][1][j];
+                t[3][j] = d[m][1][j] - d[m][3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[m][i * 4 + 0] = t[i][0] - t[i][2];
+                v[m][i * 4 + 1] = t[i][1] + t[i][2];
+                v[m][i * 4 + 2] = t[i][2] - t[i][1];
+                v[m][i * 4 + 3] = t[i][1] - t[i][3];
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            f32x4 o = {v[0][p], v[1][p], v[2][p], v[3][p]};
+            dst[(size_t)p * (S::NC8 * 2 * S::NTILE)] = o;
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    const int nsteps = a.Cin / S::KC;
+    const int C8 = a.Cin >> 3;
+    const int co_l = min(n0 + li, a.Cout - 1);
+    // U' as float4: index = ((p*C8 + c8)*2 + kh)*Cout + co ; per-lane part in uvo, the rest is wave-uniform
+    const int uvo = (hi * a.Cout + co_l) * 16;
+    const int u_c8 = 2 * a.Cout * 16, u_p = C8 * u_c8;
+
+    load_patch(0);
+    transform_store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) load_patch((s + 1) * S::KC);
+        {   // inactive waves (n0 >= Cout) run the same products on clamped rows: no divergent region around the accumulators
+            const f32x4* vb = vst + (s & 1) * S::STAGE_F4 + (size_t)hi * S::NTILE + tbi * 32 + li;
+            const int ub = s * S::NC8 * u_c8;
+            f32x4 ua[2][S::NC8], va[2][S::NC8];
+#pragma unroll
+            for (int c = 0; c < S::NC8; ++c) {
+                ua[0][c] = skp_buf_load_f32x4(urs, uvo, ub + c * u_c8, 0);
+                va[0][c] = vb[(size_t)c * (2 * S::NTILE)];
+            }
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p + 1 < 16) {
+#pragma unroll
+                    for (int c = 0; c < S::NC8; ++c) {
+                        ua[(p + 1) & 1][c] = skp_buf_load_f32x4(urs, uvo, ub + (p + 1) * u_p + c * u_c8, 0);
+                        va[(p + 1) & 1][c] = vb[(size_t)((p + 1) * S::NC8 + c) * (2 * S::NTILE)];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < S::NC8; ++c)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p & 1][c][m], va[p & 1][c][m], acc[p], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) transform_store((s + 1) & 1);
+        __syncthreads();
+    }
+    if (!wave_active) return;
+
+    // ---- output transform (in-lane) + store: lane = tile, register r = output channel ----
+    const int tg = tile0 + tbi * 32 + li;
+    if (tg >= a.nTiles) return;
+    const int b = tg / a.tilesPerImg, rem = tg - b * a.tilesPerImg;
+    const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const bool row1 = oy + 1 < a.H, col1 = ox + 1 < a.W;
+    const bool vec = col1 && ((a.W & 1) == 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= a.Cout) continue;
+        float sr[4], dr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sr[i] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+            dr[i] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+        }
+        const float bv = a.bias ? a.bias[co] : 0.f;
+        const float y00 = sr[0] + sr[1] + sr[2] + bv, y01 = dr[0] + dr[1] + dr[2] + bv;
+        const float y10 = sr[1] - sr[2] - sr[3] + bv, y11 = dr[1] - dr[2] - dr[3] + bv;
+        float* yp = a.y + ((size_t)(b * a.Cout + co) * a.H + oy) * a.W + ox;
+        if (vec) {
+            *(f32x2*)yp = f32x2{y00, y01};
+            if (row1) *(f32x2*)(yp + a.W) = f32x2{y10, y11};
+        } else {
+            yp[0] = y00;
+            if (col1) yp[1] = y01;
+            if (row1) {
+                yp[a.W] = y10;
+                if (col1) yp[a.W + 1] = y11;
+            }
+        }
+    }
+}
+
+template <int CB, int TB>
+int launch_wino(const WinoArgs& a, hipStream_t st) {
+    using S = WinoShape<CB, TB>;
+    const size_t lds = (size_t)2 * S::STAGE_F4 * sizeof(f32x4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((a.nTiles + S::NTILE - 1) / S::NTILE, (a.Cout + 32 * CB - 1) / (32 * CB));
+    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB>), grid, dim3(256), lds, st, a);
+    return skp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int skp_conv3x3_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream) {
+    if (!w || !U || Cout <= 0 || Cin <= 0) return SKP_E_BADARG;
+    if ((Cin & 7) != 0) return SKP_E_RANGE;
+    const int n = Cout * Cin;
+    hipLaunchKernelGGL(skp_wino_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)w, (float*)U, Cout, Cin, flip_transpose);
+    return skp_launch_status();
+}
+
+extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout,
+                               int H, int W, int variant, void* stream) {
+    if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return SKP_E_BADARG;
+    if ((Cout & 31) != 0) return SKP_E_RANGE;
+    WinoArgs a;
+    a.x = (const float*)x; a.U = (const float*)U; a.bias = (const float*)bias; a.y = (float*)y;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.tilesX = (W + 1) / 2;
+    a.tilesPerImg = a.tilesX * ((H + 1) / 2);
+    a.nTiles = B * a.tilesPerImg;
+    const unsigned long long xb = (unsigned long long)B * Cin * H * W * 4, ub = (unsigned long long)16 * Cin * Cout * 4;
+    if (xb >= 0x80000000ull || ub >= 0x80000000ull) return SKP_E_RANGE;     // 32-bit buffer offsets
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) variant = (Cin % 32 == 0) ? 1 : 2;     // 128-channel workgroups; a partial last group idles whole waves
+    if (variant == 1) {
+        if (Cin % 32) return SKP_E_RANGE;
+        return launch_wino<4, 1>(a, st);
+    }
+    if (Cin % 16) return SKP_E_RANGE;
+    return launch_wino<2, 2>(a, st);
+}

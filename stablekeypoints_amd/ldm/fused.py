@@ -24,14 +24,14 @@ def _resnet_forward(m: ResnetBlock2D):
         if not ops.group_norm_supported(x, m.norm1.num_groups):
             return orig(x, temb)
         h = ops.group_norm_silu(x, m.norm1)
-        h = F.conv2d(h, m.conv1.weight, None, padding=1)                 # bias folded into norm2's offset
+        h = ops.conv3x3_auto(h, m.conv1.weight)                          # bias folded into norm2's offset
         off = m.conv1.bias[None, :].expand(x.shape[0], -1)
         if m.time_emb_proj is not None and temb is not None:
             off = off + m.time_emb_proj(F.silu(temb))
         h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
         if m.conv_shortcut is not None:
             x = m.conv_shortcut(x)
-        h = F.conv2d(h, m.conv2.weight, None, padding=1)                 # bias added together with the residual
+        h = ops.conv3x3_auto(h, m.conv2.weight)                          # bias added together with the residual
         return ops.add_bias_residual(x, h, m.conv2.bias)
     return forward
 
@@ -52,9 +52,20 @@ def _transformer_forward(m: Transformer2DModel):
     return forward
 
 
+def _conv_forward(m: torch.nn.Conv2d):
+    def forward(x):
+        return ops.conv3x3_auto(x, m.weight, m.bias)
+    return forward
+
+
 def fuse_norms(module: torch.nn.Module) -> int:
     n = 0
     for mod in module.modules():
+        if (isinstance(mod, torch.nn.Conv2d) and mod.kernel_size == (3, 3) and mod.stride == (1, 1)
+                and mod.padding == (1, 1) and mod.dilation == (1, 1) and mod.groups == 1
+                and mod.padding_mode == "zeros" and "forward" not in mod.__dict__):
+            mod.forward = _conv_forward(mod)        # Upsample2D.conv and friends (resnet convs are called below)
+            continue
         if isinstance(mod, ResnetBlock2D) and "forward" not in mod.__dict__:
             mod.forward = _resnet_forward(mod); n += 1
         elif isinstance(mod, Transformer2DModel) and "forward" not in mod.__dict__:

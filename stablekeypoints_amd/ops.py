@@ -447,3 +447,89 @@ class AddBiasResidualFn(torch.autograd.Function):
 
 def add_bias_residual(a, b, bias):
     return AddBiasResidualFn.apply(a, b, bias)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3x3 / stride 1 / pad 1 convolutions of the frozen blocks: Winograd F(2x2,3x3) on the fp32 matrix cores.
+# ---------------------------------------------------------------------------------------------------------
+def conv3x3_supported(x_shape, w_shape, need_grad=True):
+    """Shapes the kernel takes (everything else stays on the library convolution)."""
+    if len(w_shape) != 4 or tuple(w_shape[2:]) != (3, 3) or len(x_shape) != 4:
+        return False
+    co, ci = int(w_shape[0]), int(w_shape[1])
+    if co % 32 or ci % 32:
+        return False
+    b, _, h, w = (int(v) for v in x_shape)
+    return max(b * ci * h * w, b * co * h * w, 16 * ci * co) * 4 < 2 ** 31
+
+
+def _wino_filters(weight, backward):
+    """Transformed filter of a frozen weight, built once per (weight storage, version) and kept resident."""
+    key = "_skp_wino_bwd" if backward else "_skp_wino_fwd"
+    hit = getattr(weight, key, None)
+    if hit is not None and hit[0] == weight._version and hit[1].device == weight.device:
+        return hit[1]
+    w = _dev(weight.detach(), "weight")
+    co, ci = w.shape[:2]
+    U = torch.empty(16 * co * ci, device=w.device, dtype=torch.float32)
+    if backward:
+        N.check(N.lib().skp_conv3x3_filter_f32(w.data_ptr(), U.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_filter_f32")
+    else:
+        N.check(N.lib().skp_conv3x3_filter_f32(w.data_ptr(), U.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_filter_f32")
+    setattr(weight, key, (weight._version, U))
+    return U
+
+
+def _conv3x3_raw(x, U, bias, cout, variant=0):
+    B, ci, H, W = x.shape
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    N.check(N.lib().skp_conv3x3_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    y.data_ptr(), B, ci, cout, H, W, int(variant), _stream()), "skp_conv3x3_f32")
+    return y
+
+
+def conv3x3_wanted(x_shape, w_shape):
+    """Supported AND large enough to fill the chip: the kernel's workgroup is 128 output channels x 32 tiles of
+    2x2 pixels; below ~half a wave of workgroups on the 256 CUs the library convolution is faster (measured,
+    profiles/r01_conv_wino.md)."""
+    if not conv3x3_supported(x_shape, w_shape):
+        return False
+    b, _, h, w = (int(v) for v in x_shape)
+    tiles = b * ((h + 1) // 2) * ((w + 1) // 2)
+    return ((tiles + 31) // 32) * ((int(w_shape[0]) + 127) // 128) >= 128
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """y = conv2d(x, weight, bias, stride 1, padding 1) with frozen weight/bias; dx is the same kernel run with the
+    rotated, transposed filter."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _dev(x, "x")
+        ctx.weight = weight
+        return _conv3x3_raw(x, _wino_filters(weight, False), bias, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w = ctx.weight
+            co, ci = w.shape[:2]
+            if conv3x3_wanted(dy.shape, (ci, co, 3, 3)):
+                dx = _conv3x3_raw(_dev(dy, "dy"), _wino_filters(w, True), None, ci)
+            else:       # too few workgroups for this kernel: library backward-data
+                dx = torch.nn.grad.conv2d_input((dy.shape[0], ci, dy.shape[2], dy.shape[3]), w, dy, padding=1)
+        return dx, None, None
+
+
+def conv3x3(x, weight, bias=None):
+    if not conv3x3_supported(x.shape, weight.shape):
+        raise ValueError(f"conv3x3: unsupported shape x {tuple(x.shape)} w {tuple(weight.shape)}")
+    return Conv3x3Fn.apply(x, weight, bias)
+
+
+def conv3x3_auto(x, weight, bias=None):
+    """The frozen blocks' 3x3 convolution: Winograd kernel where it is wanted, library convolution otherwise."""
+    if x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
+        return Conv3x3Fn.apply(x, weight, bias)
+    return torch.nn.functional.conv2d(x, weight, bias, padding=1)

@@ -375,3 +375,35 @@ def test_sd_shape_backward_is_deterministic_and_finite(ops):
     g1 = torch.autograd.grad(M.sum(), qs + ks)                  # d/dq sum_t softmax_t == 0
     for a, ref in zip(g1, grads[0]):
         assert a.abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,bias", [(2, 32, 32, 8, 8, True), (1, 64, 96, 7, 5, False), (3, 32, 160, 6, 10, True),
+                                              (8, 128, 128, 64, 64, True), (2, 320, 320, 16, 16, False),
+                                              (1, 96, 64, 33, 17, True)])
+def test_winograd_conv3x3_fwd_bwd_vs_fp64(ops, B, ci, co, H, W, bias):
+    """3x3/s1/p1 convolution of the frozen blocks (Winograd F(2x2,3x3) on fp32 MFMA) against fp64 conv2d: forward
+    (+bias), and the input gradient through the same kernel with the rotated/transposed filter.  Both workgroup
+    shapes; odd sizes exercise partial tiles, ragged tile blocks and idle channel waves."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, generator=g) if bias else None
+    gy = torch.randn(B, co, H, W, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, w.double(), None if b is None else b.double(), padding=1)
+    (ref * gy.double()).sum().backward()
+    xg, wg = x.cuda().requires_grad_(True), w.cuda()
+    bg = None if b is None else b.cuda()
+    assert ops.conv3x3_supported(xg.shape, wg.shape)
+    y = ops.conv3x3(xg, wg, bg)
+    tol = 2e-5 * ref.abs().max().item()
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=tol)
+    for variant in (1, 2):
+        yv = ops._conv3x3_raw(xg.detach(), ops._wino_filters(wg, False), bg, co, variant)
+        torch.testing.assert_close(yv.cpu().double(), ref.detach(), rtol=1e-4, atol=tol)
+    dx = ops._conv3x3_raw(gy.cuda(), ops._wino_filters(wg, True), None, ci)
+    torch.testing.assert_close(dx.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
+    (y * gy.cuda()).sum().backward()                       # autograd path (kernel or library by size)
+    torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
+    # determinism
+    assert torch.equal(ops.conv3x3(xg.detach(), wg, bg), y.detach())

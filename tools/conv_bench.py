@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Winograd conv3x3 kernel vs the library convolution: error and time per shape (fwd and bwd-data)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from stablekeypoints_amd import ops
+
+SHAPES = [  # name, B, Cin, Cout, H
+    ("vae 512^2 128->128", 8, 128, 128, 512), ("vae 256^2 128->256", 8, 128, 256, 256),
+    ("vae 256^2 256->256", 8, 256, 256, 256), ("vae 128^2 256->512", 8, 256, 512, 128),
+    ("vae 128^2 512->512", 8, 512, 512, 128), ("vae 64^2 512->512", 8, 512, 512, 64),
+    ("unet 64^2 320->320", 8, 320, 320, 64), ("unet 32^2 320->640", 8, 320, 640, 32),
+    ("unet 32^2 640->640", 8, 640, 640, 32), ("unet 16^2 640->1280", 8, 640, 1280, 16),
+    ("unet 16^2 1280->1280", 8, 1280, 1280, 16), ("unet 8^2 1280->1280", 8, 1280, 1280, 8),
+    ("unet 16^2 2560->1280", 8, 2560, 1280, 16), ("unet 32^2 1920->640", 8, 1920, 640, 32),
+    ("unet 32^2 1280->640", 8, 1280, 640, 32), ("unet 32^2 960->640", 8, 960, 640, 32),
+]
+
+
+def timeit(fn, iters=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    variants = [int(v) for v in sys.argv[1:]] or [0]
+    torch.manual_seed(0)
+    for name, B, ci, co, H in SHAPES:
+        x = torch.randn(B, ci, H, H, device="cuda")
+        w = torch.randn(co, ci, 3, 3, device="cuda") / (3 * ci ** 0.5)
+        b = torch.randn(co, device="cuda")
+        ref = F.conv2d(x, w, b, padding=1)
+        U = ops._wino_filters(w, False)
+        fl = 2 * 9 * ci * co * B * H * H / 1e9
+        t_lib = timeit(lambda: F.conv2d(x, w, b, padding=1))
+        line = f"{name:24s} lib {t_lib:6.2f} ms {fl / t_lib:6.1f} TF/s |"
+        for v in variants:
+            y = ops._conv3x3_raw(x, U, b, co, v)
+            err = ((y - ref).abs().max() / ref.abs().max()).item()
+            t = timeit(lambda: ops._conv3x3_raw(x, U, b, co, v))
+            line += f" v{v} {t:6.2f} ms {fl / t:6.1f} TF/s-eq err {err:.1e} |"
+        # backward-data
+        dy = torch.randn_like(ref)
+        Ub = ops._wino_filters(w, True)
+        dref = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1)
+        dx = ops._conv3x3_raw(dy, Ub, None, ci, 0)
+        errb = ((dx - dref).abs().max() / dref.abs().max()).item()
+        tb_lib = timeit(lambda: torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1))
+        tb = timeit(lambda: ops._conv3x3_raw(dy, Ub, None, ci, 0))
+        line += f" bwd lib {tb_lib:6.2f} ms wino {tb:6.2f} ms err {errb:.1e}"
+        print(line, flush=True)
+        del x, w, ref, U, Ub, dy, dref, dx
+
+
+if __name__ == "__main__":
+    main()
