@@ -102,7 +102,7 @@ struct PatchIdx {
     int off[4][4];          // byte offset of (row i, col j) of channel quad 0 of this tile's image, or SKP_OOB
 };
 
-template <int CB, int TB>
+template <int CB, int TB, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
     using S = WinoShape<CB, TB>;
     extern __shared__ f32x4 vst[];                   // [2][16][NC8][2][NTILE]
@@ -191,35 +191,48 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
 
     load_patch(0);
     transform_store(0);
+    // U operands travel through a ring of UD+1 positions: the position needed UD products from now is requested
+    // first, then this position's share of the next stage's patch loads.  VMEM returns in order, so everything
+    // queued behind a patch load (HBM latency) must not be needed before UD x 1024 MFMA cycles have passed.
+    constexpr int UD = 3;
+    f32x4 ua[UD + 1][S::NC8];
+#pragma unroll
+    for (int q = 0; q < UD; ++q)
+#pragma unroll
+        for (int c = 0; c < S::NC8; ++c) ua[q][c] = skp_buf_load_f32x4(urs, uvo, q * u_p + c * u_c8, 0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const bool more = s + 1 < nsteps;
-        if (more) load_patch((s + 1) * S::KC);
-        {   // inactive waves (n0 >= Cout) run the same products on clamped rows: no divergent region around the accumulators
-            const f32x4* vb = vst + (s & 1) * S::STAGE_F4 + (size_t)hi * S::NTILE + tbi * 32 + li;
-            const int ub = s * S::NC8 * u_c8;
-            f32x4 ua[2][S::NC8], va[2][S::NC8];
+        // inactive waves (n0 >= Cout) run the same products on clamped rows: no divergent region around the accumulators
+        const f32x4* vb = vst + (s & 1) * S::STAGE_F4 + (size_t)hi * S::NTILE + tbi * 32 + li;
+        const int ub = s * S::NC8 * u_c8;
+        f32x4 va[2][S::NC8];
 #pragma unroll
-            for (int c = 0; c < S::NC8; ++c) {
-                ua[0][c] = skp_buf_load_f32x4(urs, uvo, ub + c * u_c8, 0);
-                va[0][c] = vb[(size_t)c * (2 * S::NTILE)];
+        for (int c = 0; c < S::NC8; ++c) va[0][c] = vb[(size_t)c * (2 * S::NTILE)];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            {   // U for position p+UD (wrapping into the next stage; past the last stage the loads are out of range -> 0)
+                const int q = p + UD;
+                const int uo = q < 16 ? ub + q * u_p : ub + S::NC8 * u_c8 + (q - 16) * u_p;
+#pragma unroll
+                for (int c = 0; c < S::NC8; ++c) ua[q % (UD + 1)][c] = skp_buf_load_f32x4(urs, uvo, uo + c * u_c8, 0);
+            }
+            if (DBG != 1) {   // this position's quarter-channel of the next stage's patches (unused garbage after the last stage)
+                const int m = p >> 2, i = p & 3;
+                const int so = ((s + 1) * S::KC + m) * HW * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[m][i][j] = skp_buf_load_f32(xrs, pi.off[i][j], so, 0);
+            }
+            if (p + 1 < 16) {
+#pragma unroll
+                for (int c = 0; c < S::NC8; ++c) va[(p + 1) & 1][c] = vb[(size_t)((p + 1) * S::NC8 + c) * (2 * S::NTILE)];
             }
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                if (p + 1 < 16) {
+            for (int c = 0; c < S::NC8; ++c)
 #pragma unroll
-                    for (int c = 0; c < S::NC8; ++c) {
-                        ua[(p + 1) & 1][c] = skp_buf_load_f32x4(urs, uvo, ub + (p + 1) * u_p + c * u_c8, 0);
-                        va[(p + 1) & 1][c] = vb[(size_t)((p + 1) * S::NC8 + c) * (2 * S::NTILE)];
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < S::NC8; ++c)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p & 1][c][m], va[p & 1][c][m], acc[p], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int m = 0; m < 4; ++m)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p % (UD + 1)][c][m], va[p & 1][c][m], acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) transform_store((s + 1) & 1);
         __syncthreads();
@@ -262,19 +275,19 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
     }
 }
 
-template <int CB, int TB>
+template <int CB, int TB, int DBG = 0>
 int launch_wino(const WinoArgs& a, hipStream_t st) {
     using S = WinoShape<CB, TB>;
     const size_t lds = (size_t)2 * S::STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB>,
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB, DBG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((a.nTiles + S::NTILE - 1) / S::NTILE, (a.Cout + 32 * CB - 1) / (32 * CB));
-    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB, DBG>), grid, dim3(256), lds, st, a);
     return skp_launch_status();
 }
 
@@ -304,6 +317,7 @@ extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, v
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
     hipStream_t st = (hipStream_t)stream;
     if (variant == 0) variant = (Cin % 32 == 0) ? 1 : 2;     // 128-channel workgroups; a partial last group idles whole waves
+    if (variant == 101) return launch_wino<4, 1, 1>(a, st);      // timing experiment: no patch reloads (wrong results)
     if (variant == 1) {
         if (Cin % 32) return SKP_E_RANGE;
         return launch_wino<4, 1>(a, st);
