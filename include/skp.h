@@ -153,10 +153,14 @@ int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias,
  *   backward-data convolution instead: pass the SAME w [Cw_out,Cw_in,3,3] with Cout = Cw_in, Cin = Cw_out.
  * skp_conv3x3_f32: y [B,Cout,H,W] = conv(x [B,Cin,H,W]) (+ bias[Cout] if non-NULL).  Cout % 32 == 0;
  *   variant 0 = auto, 1 = workgroup of 128 channels x 32 tiles (Cin % 32 == 0), 2 = 64 channels x 64 tiles
- *   (Cin % 16 == 0).  x and U must each be < 2 GiB (32-bit buffer offsets), else SKP_E_RANGE. */
+ *   (Cin % 16 == 0).  x and U must each be < 2 GiB (32-bit buffer offsets), else SKP_E_RANGE.
+ *   Layers with too few workgroups for the 256 CUs are split over input channels (deterministic: partial outputs in
+ *   `workspace`, summed in fixed order by a second kernel); skp_conv3x3_workspace gives the bytes needed (0 = no
+ *   split).  workspace NULL forces the unsplit launch. */
 int skp_conv3x3_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream);
-int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
-                    int variant, void* stream);
+int64_t skp_conv3x3_workspace(int B, int Cin, int Cout, int H, int W, int variant);
+int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin, int Cout,
+                    int H, int W, int variant, void* stream);
 
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects

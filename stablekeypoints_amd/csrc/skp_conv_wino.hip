@@ -87,6 +87,8 @@ struct WinoArgs {
     int B, Cin, Cout, H, W;
     int tilesX, tilesPerImg, nTiles;
     unsigned x_bytes, u_bytes;
+    int steps;              // channel stages per workgroup (= Cin / KC / splits)
+    size_t y_split_stride;  // elements between the partial outputs of consecutive splits (blockIdx.z)
 };
 
 template <int CB, int TB>
@@ -182,14 +184,15 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    const int nsteps = a.Cin / S::KC;
+    const int nsteps = a.steps;
+    const int cin_begin = blockIdx.z * nsteps * S::KC;           // split-K over input channels
     const int C8 = a.Cin >> 3;
     const int co_l = min(n0 + li, a.Cout - 1);
     // U' as float4: index = ((p*C8 + c8)*2 + kh)*Cout + co ; per-lane part in uvo, the rest is wave-uniform
     const int uvo = (hi * a.Cout + co_l) * 16;
     const int u_c8 = 2 * a.Cout * 16, u_p = C8 * u_c8;
 
-    load_patch(0);
+    load_patch(cin_begin);
     transform_store(0);
     // U operands travel through a ring of UD+1 positions: the position needed UD products from now is requested
     // first, then this position's share of the next stage's patch loads.  VMEM returns in order, so everything
@@ -199,13 +202,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
 #pragma unroll
     for (int q = 0; q < UD; ++q)
 #pragma unroll
-        for (int c = 0; c < S::NC8; ++c) ua[q][c] = skp_buf_load_f32x4(urs, uvo, q * u_p + c * u_c8, 0);
+        for (int c = 0; c < S::NC8; ++c) ua[q][c] = skp_buf_load_f32x4(urs, uvo, (cin_begin >> 3) * u_c8 + q * u_p + c * u_c8, 0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const bool more = s + 1 < nsteps;
         // inactive waves (n0 >= Cout) run the same products on clamped rows: no divergent region around the accumulators
         const f32x4* vb = vst + (s & 1) * S::STAGE_F4 + (size_t)hi * S::NTILE + tbi * 32 + li;
-        const int ub = s * S::NC8 * u_c8;
+        const int ub = ((cin_begin >> 3) + s * S::NC8) * u_c8;
         f32x4 va[2][S::NC8];
 #pragma unroll
         for (int c = 0; c < S::NC8; ++c) va[0][c] = vb[(size_t)c * (2 * S::NTILE)];
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
             }
             if (DBG != 1) {   // this position's quarter-channel of the next stage's patches (unused garbage after the last stage)
                 const int m = p >> 2, i = p & 3;
-                const int so = ((s + 1) * S::KC + m) * HW * 4;
+                const int so = (cin_begin + (s + 1) * S::KC + m) * HW * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) d[m][i][j] = skp_buf_load_f32(xrs, pi.off[i][j], so, 0);
             }
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
         const float bv = a.bias ? a.bias[co] : 0.f;
         const float y00 = sr[0] + sr[1] + sr[2] + bv, y01 = dr[0] + dr[1] + dr[2] + bv;
         const float y10 = sr[1] - sr[2] - sr[3] + bv, y11 = dr[1] - dr[2] - dr[3] + bv;
-        float* yp = a.y + ((size_t)(b * a.Cout + co) * a.H + oy) * a.W + ox;
+        float* yp = a.y + blockIdx.z * a.y_split_stride + ((size_t)(b * a.Cout + co) * a.H + oy) * a.W + ox;
         if (vec) {
             *(f32x2*)yp = f32x2{y00, y01};
             if (row1) *(f32x2*)(yp + a.W) = f32x2{y10, y11};
@@ -275,8 +278,22 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
     }
 }
 
+// y[i] = sum_z part[z][i] (+ bias[channel]) in fixed order: the deterministic tail of the split-K launches
+__global__ void skp_wino_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                       size_t n4, size_t stride, int splits, int HW4, int Cout) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = ((const f32x4*)part)[i];
+    for (int z = 1; z < splits; ++z) acc += ((const f32x4*)(part + z * stride))[i];
+    if (bias) {
+        const float bv = bias[(i / HW4) % Cout];
+        acc += f32x4{bv, bv, bv, bv};
+    }
+    ((f32x4*)y)[i] = acc;
+}
+
 template <int CB, int TB, int DBG = 0>
-int launch_wino(const WinoArgs& a, hipStream_t st) {
+int launch_wino(const WinoArgs& a, int splits, hipStream_t st) {
     using S = WinoShape<CB, TB>;
     const size_t lds = (size_t)2 * S::STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
@@ -286,7 +303,7 @@ int launch_wino(const WinoArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((a.nTiles + S::NTILE - 1) / S::NTILE, (a.Cout + 32 * CB - 1) / (32 * CB));
+    dim3 grid((a.nTiles + S::NTILE - 1) / S::NTILE, (a.Cout + 32 * CB - 1) / (32 * CB), splits);
     hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB, DBG>), grid, dim3(256), lds, st, a);
     return skp_launch_status();
 }
@@ -302,12 +319,50 @@ extern "C" int skp_conv3x3_filter_f32(const void* w, void* U, int Cout, int Cin,
     return skp_launch_status();
 }
 
-extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout,
-                               int H, int W, int variant, void* stream) {
+// Split-K choice: fill the 256 CUs (one workgroup each: 512 registers per lane, 128 KB LDS).  Cost model in
+// microseconds: rounds x (stages + ~1 stage of prologue/epilogue) x stage time, plus the reduce pass.
+static int wino_pick_split(int wgs, int nsteps, double stage_us, double out_bytes) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 16; ++S) {
+        if (nsteps % S) continue;
+        const int rounds = (wgs * S + 255) / 256;
+        double cost = rounds * (nsteps / S + 1.0) * stage_us;
+        if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 4.0e6;
+        if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
+    }
+    return best;
+}
+
+static int wino_plan(int B, int Cin, int Cout, int H, int W, int variant, int* v_out) {
+    if (variant == 0) variant = (Cin % 32 == 0) ? 1 : 2;   // 128-channel workgroups; a partial last group idles whole waves
+    const int tiles = B * ((W + 1) / 2) * ((H + 1) / 2);
+    const int ntile = variant == 2 ? 64 : 32, cg = variant == 2 ? 64 : 128, kc = variant == 2 ? 16 : 32;
+    *v_out = variant;
+    if (Cin % kc) return 0;
+    const int wgs = ((tiles + ntile - 1) / ntile) * ((Cout + cg - 1) / cg);
+    if ((H * W) % 4) return 1;                              // the reduce pass works on float4 within a channel plane
+    return wino_pick_split(wgs, Cin / kc, variant == 2 ? 3.4 : 6.8, (double)B * Cout * H * W * 4);
+}
+
+extern "C" int64_t skp_conv3x3_workspace(int B, int Cin, int Cout, int H, int W, int variant) {
+    int v;
+    const int S = wino_plan(B, Cin, Cout, H, W, variant, &v);
+    return S > 1 ? (int64_t)S * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin,
+                               int Cout, int H, int W, int variant, void* stream) {
     if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return SKP_E_BADARG;
     if ((Cout & 31) != 0) return SKP_E_RANGE;
+    const bool dbg = variant == 101;
+    if (dbg) variant = 1;
+    int v;
+    int S = wino_plan(B, Cin, Cout, H, W, variant, &v);
+    if (S == 0) return SKP_E_RANGE;
+    if (!workspace) S = 1;
     WinoArgs a;
-    a.x = (const float*)x; a.U = (const float*)U; a.bias = (const float*)bias; a.y = (float*)y;
+    a.x = (const float*)x; a.U = (const float*)U;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.tilesX = (W + 1) / 2;
     a.tilesPerImg = a.tilesX * ((H + 1) / 2);
@@ -315,13 +370,20 @@ extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, v
     const unsigned long long xb = (unsigned long long)B * Cin * H * W * 4, ub = (unsigned long long)16 * Cin * Cout * 4;
     if (xb >= 0x80000000ull || ub >= 0x80000000ull) return SKP_E_RANGE;     // 32-bit buffer offsets
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+    const size_t out_elems = (size_t)B * Cout * H * W;
+    a.steps = Cin / (v == 2 ? 16 : 32) / S;
+    a.y_split_stride = out_elems;
+    a.y = S > 1 ? (float*)workspace : (float*)y;
+    a.bias = S > 1 ? nullptr : (const float*)bias;
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 0) variant = (Cin % 32 == 0) ? 1 : 2;     // 128-channel workgroups; a partial last group idles whole waves
-    if (variant == 101) return launch_wino<4, 1, 1>(a, st);      // timing experiment: no patch reloads (wrong results)
-    if (variant == 1) {
-        if (Cin % 32) return SKP_E_RANGE;
-        return launch_wino<4, 1>(a, st);
-    }
-    if (Cin % 16) return SKP_E_RANGE;
-    return launch_wino<2, 2>(a, st);
+    int rc;
+    if (dbg) rc = launch_wino<4, 1, 1>(a, S, st);           // timing experiment: no patch reloads (wrong results)
+    else if (v == 1) rc = launch_wino<4, 1>(a, S, st);
+    else rc = launch_wino<2, 2>(a, S, st);
+    if (rc || S == 1) return rc;
+    if ((H * W) % 4) return SKP_E_RANGE;                    // (wino_plan only splits when the reduce pass applies)
+    const size_t n4 = out_elems / 4;
+    hipLaunchKernelGGL(skp_wino_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                       (const float*)bias, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
+    return skp_launch_status();
 }

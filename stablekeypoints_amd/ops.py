@@ -480,23 +480,24 @@ def _wino_filters(weight, backward):
     return U
 
 
-def _conv3x3_raw(x, U, bias, cout, variant=0):
+def _conv3x3_raw(x, U, bias, cout, variant=0, split=True):
     B, ci, H, W = x.shape
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    nbytes = N.lib().skp_conv3x3_workspace(B, ci, cout, H, W, int(variant)) if split else 0
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     N.check(N.lib().skp_conv3x3_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                    y.data_ptr(), B, ci, cout, H, W, int(variant), _stream()), "skp_conv3x3_f32")
+                                    y.data_ptr(), ws.data_ptr() if ws is not None else None, B, ci, cout, H, W,
+                                    int(variant), _stream()), "skp_conv3x3_f32")
     return y
 
 
 def conv3x3_wanted(x_shape, w_shape):
-    """Supported AND large enough to fill the chip: the kernel's workgroup is 128 output channels x 32 tiles of
-    2x2 pixels; below ~half a wave of workgroups on the 256 CUs the library convolution is faster (measured,
-    profiles/r01_conv_wino.md)."""
+    """Supported AND enough 2x2 tiles to fill the 32-tile MFMA column blocks (layers with few workgroups are split
+    over input channels inside the library call, so the channel counts do not matter here)."""
     if not conv3x3_supported(x_shape, w_shape):
         return False
     b, _, h, w = (int(v) for v in x_shape)
-    tiles = b * ((h + 1) // 2) * ((w + 1) // 2)
-    return ((tiles + 31) // 32) * ((int(w_shape[0]) + 127) // 128) >= 128
+    return b * ((h + 1) // 2) * ((w + 1) // 2) >= 128
 
 
 class Conv3x3Fn(torch.autograd.Function):

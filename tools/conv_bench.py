@@ -42,10 +42,13 @@ def main():
         t_lib = timeit(lambda: F.conv2d(x, w, b, padding=1))
         line = f"{name:24s} lib {t_lib:6.2f} ms {fl / t_lib:6.1f} TF/s |"
         for v in variants:
-            y = ops._conv3x3_raw(x, U, b, co, v)
-            err = ((y - ref).abs().max() / ref.abs().max()).item()
-            t = timeit(lambda: ops._conv3x3_raw(x, U, b, co, v))
-            line += f" v{v} {t:6.2f} ms {fl / t:6.1f} TF/s-eq err {err:.1e} |"
+            for split in (False, True):
+                if split and not ops.N.lib().skp_conv3x3_workspace(B, ci, co, H, H, v):
+                    continue
+                y = ops._conv3x3_raw(x, U, b, co, v, split)
+                err = ((y - ref).abs().max() / ref.abs().max()).item()
+                t = timeit(lambda: ops._conv3x3_raw(x, U, b, co, v, split))
+                line += f" v{v}{'s' if split else ' '} {t:6.2f} ms {fl / t:6.1f} TF/s-eq err {err:.1e} |"
         # backward-data
         dy = torch.randn_like(ref)
         Ub = ops._wino_filters(w, True)

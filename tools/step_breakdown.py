@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Classify the kernels of a rocprofv3 `--kernel-trace -f csv` run of bench.py into kernel classes, over a
+steady-state window: the last N optimisation steps, delimited by the Adam (multi_tensor_apply) launches.
+usage: step_breakdown.py <run_kernel_trace.csv> [N=2]"""
+import csv
+import sys
+
+CLASSES = [
+    ("skp Winograd conv3x3", ("skp_wino",)),
+    ("skp flash self-attention", ("skp_self_attn",)),
+    ("skp fused GroupNorm+SiLU / bias+residual", ("skp_group_norm", "skp_gn_", "skp_add_bias")),
+    ("skp map/cross-attn/selection/loss/gemm", ("skp_",)),
+    ("conv (MIOpen)", ("igemm", "Igemm", "conv", "Conv", "winograd", "Winograd", "gridwise_convolution", "naive_conv",
+                       "SubTensorOpWithScalar", "batched_transpose", "Im2Col", "Col2Im", "kernel_grouped_conv")),
+    ("gemm (hipBLASLt/rocBLAS)", ("Cijk", "gemm", "Gemm")),
+    ("softmax (ATen)", ("softmax", "SoftMax")),
+    ("norm (ATen)", ("layer_norm", "LayerNorm", "GroupNorm", "RowwiseMoments")),
+    ("elementwise / copy (ATen)", ("elementwise", "Elementwise", "vectorized", "copy", "Copy", "CatArray", "upsample",
+                                   "index", "fill", "reduce", "Reduce")),
+]
+
+
+def main():
+    path = sys.argv[1]
+    nwin = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    rows = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
+    rows.sort()
+    # one optimizer step = one burst of multi_tensor_apply kernels; boundary = end of the last kernel of a burst
+    bounds, last = [], None
+    for st, en, name in rows:
+        if "multi_tensor_apply" in name:
+            if last is not None and st - last < 2_000_000:
+                bounds[-1] = en
+            else:
+                bounds.append(en)
+            last = en
+    t0, t1 = bounds[-1 - nwin], bounds[-1]
+    tot, names = {}, {}
+    for st, en, name in rows:
+        if st < t0 or en > t1:
+            continue
+        for cls, keys in CLASSES:
+            if any(k in name for k in keys):
+                break
+        else:
+            cls = "other"
+        tot[cls] = tot.get(cls, 0.0) + (en - st)
+        d = names.setdefault(cls, {})
+        a = d.setdefault(name[:100], [0.0, 0])
+        a[0] += en - st; a[1] += 1
+    total = sum(tot.values())
+    print(f"window {(t1 - t0) / nwin / 1e6:.2f} ms/step, kernel time {total / nwin / 1e6:.2f} ms/step "
+          f"(GPU busy {100 * total / (t1 - t0):.0f} %), {nwin} steady-state steps\n")
+    print("| class | ms/step | % |\n|---|---|---|")
+    for cls, ns in sorted(tot.items(), key=lambda kv: -kv[1]):
+        print(f"| {cls} | {ns / nwin / 1e6:.2f} | {100 * ns / total:.1f} |")
+    print()
+    for cls in ("conv (MIOpen)", "skp Winograd conv3x3", "elementwise / copy (ATen)", "other"):
+        print(f"top kernels in '{cls}':")
+        for n, (ns, c) in sorted(names.get(cls, {}).items(), key=lambda kv: -kv[1][0])[:8]:
+            print(f"  {ns / nwin / 1e6:7.2f} ms/step  {c / nwin:6.1f} calls/step  {n}")
+
+
+if __name__ == "__main__":
+    main()
