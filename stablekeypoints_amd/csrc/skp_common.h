@@ -59,3 +59,19 @@ __device__ __forceinline__ float skp_block_sum_256(float v, float* red) {
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+
+// Raw buffer loads: wave-uniform base in SGPRs, 32-bit per-lane byte offset, scalar offset for the channel step;
+// an offset with bit 31 set is out of range for the descriptor and returns 0 (used for the zero padding).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ float skp_buf_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x4 skp_buf_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ __forceinline__ i32x4 skp_make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));      // stride 0
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+#define SKP_OOB ((int)0x80000000)

@@ -18,22 +18,6 @@
 
 namespace {
 
-// Raw buffer loads: wave-uniform base in SGPRs, 32-bit per-lane byte offset, scalar offset for the channel step;
-// an offset with bit 31 set is out of range for the descriptor and returns 0 (used for the zero padding).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ float skp_buf_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-__device__ f32x4 skp_buf_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ __forceinline__ i32x4 skp_make_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long v = (unsigned long long)p;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));      // stride 0
-    r[2] = (int)bytes;
-    r[3] = 0x00020000;
-    return r;
-}
-#define SKP_OOB ((int)0x80000000)
-
 // ---- filter transform: U'[p][ci/8][(ci%8)/4][co][ci%4] = (G g G^T)[p]  ------------------------------------
 // flip_t = 0: g = w[co][ci]            (forward)
 // flip_t = 1: g = rot180(w[ci][co])    (backward-data: a convolution with Cin and Cout swapped)
@@ -104,7 +88,7 @@ struct PatchIdx {
     int off[4][4];          // byte offset of (row i, col j) of channel quad 0 of this tile's image, or SKP_OOB
 };
 
-template <int CB, int TB, int DBG = 0>
+template <int CB, int TB>
 __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
     using S = WinoShape<CB, TB>;
     extern __shared__ f32x4 vst[];                   // [2][16][NC8][2][NTILE]
@@ -220,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
 #pragma unroll
                 for (int c = 0; c < S::NC8; ++c) ua[q % (UD + 1)][c] = skp_buf_load_f32x4(urs, uvo, uo + c * u_c8, 0);
             }
-            if (DBG != 1) {   // this position's quarter-channel of the next stage's patches (unused garbage after the last stage)
+            {   // this position's quarter-channel of the next stage's patches (unused garbage after the last stage)
                 const int m = p >> 2, i = p & 3;
                 const int so = (cin_begin + (s + 1) * S::KC + m) * HW * 4;
 #pragma unroll
@@ -292,19 +276,19 @@ __global__ void skp_wino_reduce_kernel(const float* __restrict__ part, const flo
     ((f32x4*)y)[i] = acc;
 }
 
-template <int CB, int TB, int DBG = 0>
+template <int CB, int TB>
 int launch_wino(const WinoArgs& a, int splits, hipStream_t st) {
     using S = WinoShape<CB, TB>;
     const size_t lds = (size_t)2 * S::STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB, DBG>,
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((a.nTiles + S::NTILE - 1) / S::NTILE, (a.Cout + 32 * CB - 1) / (32 * CB), splits);
-    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB, DBG>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB>), grid, dim3(256), lds, st, a);
     return skp_launch_status();
 }
 
@@ -355,8 +339,6 @@ extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, v
                                int Cout, int H, int W, int variant, void* stream) {
     if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return SKP_E_BADARG;
     if ((Cout & 31) != 0) return SKP_E_RANGE;
-    const bool dbg = variant == 101;
-    if (dbg) variant = 1;
     int v;
     int S = wino_plan(B, Cin, Cout, H, W, variant, &v);
     if (S == 0) return SKP_E_RANGE;
@@ -377,8 +359,7 @@ extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, v
     a.bias = S > 1 ? nullptr : (const float*)bias;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (dbg) rc = launch_wino<4, 1, 1>(a, S, st);           // timing experiment: no patch reloads (wrong results)
-    else if (v == 1) rc = launch_wino<4, 1>(a, S, st);
+    if (v == 1) rc = launch_wino<4, 1>(a, S, st);
     else rc = launch_wino<2, 2>(a, S, st);
     if (rc || S == 1) return rc;
     if ((H * W) % 4) return SKP_E_RANGE;                    // (wino_plan only splits when the reduce pass applies)
