@@ -162,6 +162,17 @@ int64_t skp_conv3x3_workspace(int B, int Cin, int Cout, int H, int W, int varian
 int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin, int Cout,
                     int H, int W, int variant, void* stream);
 
+/* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
+ *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0
+ * _bwd writes dp [rows, 2*inner] = d loss / d p given dy [rows, inner]. */
+int skp_geglu_fwd_f32(const float* p, float* y, int64_t rows, int inner, void* stream);
+int skp_geglu_bwd_f32(const float* p, const float* dy, float* dp, int64_t rows, int inner, void* stream);
+
+/* Layout changes around the transformer blocks (Transformer2DModel [third party]): y[b,p,c] = x[b,c,p] and back,
+ * the way back adding the block's residual [B,C,HW] (may be NULL) in the same pass.  C % 4 == 0, HW % 4 == 0. */
+int skp_nchw_to_tokens_f32(const float* x, float* y, int B, int C, int HW, void* stream);
+int skp_tokens_to_nchw_f32(const float* t, const float* residual, float* y, int B, int C, int HW, void* stream);
+
 /* Per-token statistics of a reduced map M [T,R,R] (eval.py:39-111, ptp_utils.py:95-108):
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects
  *                         (first index wins ties; radius 0.05*R masking between maxima)

@@ -257,3 +257,137 @@ extern "C" int skp_add_bias_residual_f32(const float* a, const float* b, const f
                        out, C, HW / 4, total4);
     return skp_launch_status();
 }
+
+// GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party]: h, gate = proj(x).chunk(2, -1);
+// h * gelu(gate), exact erf form) on the projection p [rows, 2*inner] in one pass per direction, instead of
+// strided gelu / mul kernels forward and gelu_backward / two muls / two slice copies backward.
+__device__ __forceinline__ float skp_gelu(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float skp_gelu_grad(float g) {
+    return 0.5f * (1.f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+__global__ __launch_bounds__(256) void skp_geglu_fwd_kernel(const float* __restrict__ p, float* __restrict__ y, int inner4,
+                                                            long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long row = i / inner4;
+        const int c4 = (int)(i - row * inner4);
+        const f32x4* pr = (const f32x4*)p + row * (2 * inner4);
+        const f32x4 h = pr[c4], g = pr[inner4 + c4];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = h[j] * skp_gelu(g[j]);
+        ((f32x4*)y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void skp_geglu_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dy,
+                                                            float* __restrict__ dp, int inner4, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long row = i / inner4;
+        const int c4 = (int)(i - row * inner4);
+        const f32x4* pr = (const f32x4*)p + row * (2 * inner4);
+        f32x4* dr = (f32x4*)dp + row * (2 * inner4);
+        const f32x4 h = pr[c4], g = pr[inner4 + c4], d = ((const f32x4*)dy)[i];
+        f32x4 dh, dg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dh[j] = d[j] * skp_gelu(g[j]);
+            dg[j] = d[j] * h[j] * skp_gelu_grad(g[j]);
+        }
+        dr[c4] = dh;
+        dr[inner4 + c4] = dg;
+    }
+}
+
+extern "C" int skp_geglu_fwd_f32(const float* p, float* y, int64_t rows, int inner, void* stream) {
+    if (!p || !y || rows <= 0 || inner <= 0) return SKP_E_BADARG;
+    if (inner % 4) return SKP_E_RANGE;
+    const long total4 = rows * (inner / 4);
+    long blocks = (total4 + 256 * 2 - 1) / (256 * 2);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(skp_geglu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, y, inner / 4, total4);
+    return skp_launch_status();
+}
+
+extern "C" int skp_geglu_bwd_f32(const float* p, const float* dy, float* dp, int64_t rows, int inner, void* stream) {
+    if (!p || !dy || !dp || rows <= 0 || inner <= 0) return SKP_E_BADARG;
+    if (inner % 4) return SKP_E_RANGE;
+    const long total4 = rows * (inner / 4);
+    long blocks = (total4 + 256 * 2 - 1) / (256 * 2);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(skp_geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, dy, dp, inner / 4,
+                       total4);
+    return skp_launch_status();
+}
+
+// Layout changes around the transformer blocks (Transformer2DModel [third party]: NCHW <-> tokens permutes), as LDS-tiled
+// transposes with coalesced float4 traffic on both sides; the way back also adds the block's residual in the same pass.
+//   to_tokens: y[b, p, c] = x[b, c, p]
+//   to_nchw  : y[b, c, p] = t[b, p, c] (+ res[b, c, p])
+template <bool TO_TOKENS>
+__global__ __launch_bounds__(256) void skp_layout_kernel(const float* __restrict__ src, const float* __restrict__ res,
+                                                         float* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, p0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, q = tid & 15, r = tid >> 4;       // float4 column, row (16 rows per pass)
+    const size_t base = (size_t)b * C * HW;
+    if (TO_TOKENS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // read x[c][p..p+3]
+            const int c = c0 + r + 16 * k, p = p0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (c < C && p < HW) v = *(const f32x4*)(src + base + (size_t)c * HW + p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[r + 16 * k][4 * q + j] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // write y[p][c..c+3]
+            const int p = p0 + r + 16 * k, c = c0 + 4 * q;
+            if (p < HW && c < C) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = tile[4 * q + j][r + 16 * k];
+                *(f32x4*)(dst + base + (size_t)p * C + c) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // read t[p][c..c+3]
+            const int p = p0 + r + 16 * k, c = c0 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < HW && c < C) v = *(const f32x4*)(src + base + (size_t)p * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[4 * q + j][r + 16 * k] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // write y[c][p..p+3] (+ res)
+            const int c = c0 + r + 16 * k, p = p0 + 4 * q;
+            if (c < C && p < HW) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = tile[r + 16 * k][4 * q + j];
+                const size_t o = base + (size_t)c * HW + p;
+                if (res) v += *(const f32x4*)(res + o);
+                *(f32x4*)(dst + o) = v;
+            }
+        }
+    }
+}
+
+extern "C" int skp_nchw_to_tokens_f32(const float* x, float* y, int B, int C, int HW, void* stream) {
+    if (!x || !y || B <= 0 || C <= 0 || HW <= 0) return SKP_E_BADARG;
+    if ((C % 4) || (HW % 4) || B > 65535) return SKP_E_RANGE;
+    hipLaunchKernelGGL(skp_layout_kernel<true>, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x,
+                       (const float*)nullptr, y, C, HW);
+    return skp_launch_status();
+}
+
+extern "C" int skp_tokens_to_nchw_f32(const float* t, const float* residual, float* y, int B, int C, int HW, void* stream) {
+    if (!t || !y || B <= 0 || C <= 0 || HW <= 0) return SKP_E_BADARG;
+    if ((C % 4) || (HW % 4) || B > 65535) return SKP_E_RANGE;
+    hipLaunchKernelGGL(skp_layout_kernel<false>, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, t,
+                       residual, y, C, HW);
+    return skp_launch_status();
+}

@@ -55,7 +55,11 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        h, gate = self.proj(x).chunk(2, dim=-1)
+        p = self.proj(x)
+        if p.is_cuda and p.dtype == torch.float32 and p.shape[-1] % 8 == 0:
+            from .. import ops
+            return ops.geglu(p)                       # one fused pass per direction on the HIP kernel
+        h, gate = p.chunk(2, dim=-1)
         return h * F.gelu(gate)
 
 

@@ -42,13 +42,21 @@ def _transformer_forward(m: Transformer2DModel):
     def forward(x, context=None):
         if not ops.group_norm_supported(x, m.norm.num_groups):
             return orig(x, context)
-        b, c, hh, ww = x.shape
-        h = m.proj_in(ops.group_norm_silu(x, m.norm, silu=False))
-        h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, h.shape[1])
+        h = ops.group_norm_silu(x, m.norm, silu=False)
+        if not ops.layout_supported(h):
+            b, c, hh, ww = x.shape
+            h = m.proj_in(h).permute(0, 2, 3, 1).reshape(b, hh * ww, -1)
+            for blk in m.transformer_blocks:
+                h = blk(h, context=context)
+            return m.proj_out(h.reshape(b, hh, ww, -1).permute(0, 3, 1, 2)) + x
+        # token layout throughout: the 1x1 convolutions are nn.Linear over tokens (bias fused in the GEMM), the two
+        # permutes are tiled transposes and the residual add rides on the way back
+        t = ops.nchw_to_tokens(h)
+        t = F.linear(t, m.proj_in.weight.flatten(1), m.proj_in.bias)
         for blk in m.transformer_blocks:
-            h = blk(h, context=context)
-        h = h.reshape(b, hh, ww, -1).permute(0, 3, 1, 2)
-        return m.proj_out(h) + x
+            t = blk(t, context=context)
+        t = F.linear(t, m.proj_out.weight.flatten(1), m.proj_out.bias)
+        return ops.tokens_to_nchw_add(t, x)
     return forward
 
 

@@ -534,3 +534,84 @@ def conv3x3_auto(x, weight, bias=None):
     if x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
         return Conv3x3Fn.apply(x, weight, bias)
     return torch.nn.functional.conv2d(x, weight, bias, padding=1)
+
+
+class GEGLUFn(torch.autograd.Function):
+    """h * gelu(gate) on the feed-forward projection [.., 2*inner] (h = first half, gate = second half)."""
+
+    @staticmethod
+    def forward(ctx, proj):
+        proj = _dev(proj, "proj")
+        inner = proj.shape[-1] // 2
+        rows = proj.numel() // (2 * inner)
+        y = torch.empty(*proj.shape[:-1], inner, device=proj.device, dtype=torch.float32)
+        N.check(N.lib().skp_geglu_fwd_f32(proj.data_ptr(), y.data_ptr(), rows, inner, _stream()), "skp_geglu_fwd_f32")
+        ctx.save_for_backward(proj)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (proj,) = ctx.saved_tensors
+        dy = _dev(dy, "dy")
+        inner = proj.shape[-1] // 2
+        dp = torch.empty_like(proj)
+        N.check(N.lib().skp_geglu_bwd_f32(proj.data_ptr(), dy.data_ptr(), dp.data_ptr(), proj.numel() // (2 * inner), inner,
+                                          _stream()), "skp_geglu_bwd_f32")
+        return dp
+
+
+def geglu(proj):
+    return GEGLUFn.apply(proj)
+
+
+def _to_tokens_raw(x):
+    B, C, H, W = x.shape
+    y = torch.empty(B, H * W, C, device=x.device, dtype=torch.float32)
+    N.check(N.lib().skp_nchw_to_tokens_f32(x.data_ptr(), y.data_ptr(), B, C, H * W, _stream()), "skp_nchw_to_tokens_f32")
+    return y
+
+
+def _to_nchw_raw(t, res, H, W):
+    B, HW, C = t.shape
+    y = torch.empty(B, C, H, W, device=t.device, dtype=torch.float32)
+    N.check(N.lib().skp_tokens_to_nchw_f32(t.data_ptr(), res.data_ptr() if res is not None else None, y.data_ptr(), B, C,
+                                           HW, _stream()), "skp_tokens_to_nchw_f32")
+    return y
+
+
+class NchwToTokensFn(torch.autograd.Function):
+    """[B,C,H,W] -> [B,H*W,C] (the permute(0,2,3,1).reshape of Transformer2DModel) as one tiled transpose."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[2], x.shape[3])
+        return _to_tokens_raw(_dev(x, "x"))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _to_nchw_raw(_dev(dy, "dy"), None, *ctx.hw)
+
+
+class TokensToNchwAddFn(torch.autograd.Function):
+    """[B,H*W,C] -> [B,C,H,W] plus the block residual in the same pass."""
+
+    @staticmethod
+    def forward(ctx, t, res):
+        return _to_nchw_raw(_dev(t, "t"), _dev(res, "res"), res.shape[2], res.shape[3])
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _dev(dy, "dy")
+        return (_to_tokens_raw(dy) if ctx.needs_input_grad[0] else None), (dy if ctx.needs_input_grad[1] else None)
+
+
+def layout_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def nchw_to_tokens(x):
+    return NchwToTokensFn.apply(x)
+
+
+def tokens_to_nchw_add(t, res):
+    return TokensToNchwAddFn.apply(t, res)

@@ -407,3 +407,29 @@ def test_winograd_conv3x3_fwd_bwd_vs_fp64(ops, B, ci, co, H, W, bias):
     torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
     # determinism
     assert torch.equal(ops.conv3x3(xg.detach(), wg, bg), y.detach())
+
+
+def test_geglu_and_layout_kernels(ops):
+    """Fused GEGLU (fwd/bwd) vs torch in fp64; NCHW<->token transposes (+ residual) exact, with their gradients."""
+    g = torch.Generator().manual_seed(23)
+    p = torch.randn(3, 50, 2 * 72, generator=g)
+    w = torch.randn(3, 50, 72, generator=g)
+    pd = p.double().requires_grad_(True)
+    h, gate = pd.chunk(2, dim=-1)
+    ref = h * torch.nn.functional.gelu(gate)
+    (ref * w.double()).sum().backward()
+    pg = p.cuda().requires_grad_(True)
+    y = ops.geglu(pg)
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    (y * w.cuda()).sum().backward()
+    torch.testing.assert_close(pg.grad.cpu().double(), pd.grad, rtol=1e-5, atol=1e-6)
+    for (B, C, H, W) in [(2, 64, 8, 8), (3, 100, 6, 10), (1, 320, 64, 64)]:
+        x = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_(True)
+        r = torch.randn(B, C, H, W, generator=g).cuda().requires_grad_(True)
+        t = ops.nchw_to_tokens(x)
+        assert torch.equal(t, x.permute(0, 2, 3, 1).reshape(B, H * W, C))
+        back = ops.tokens_to_nchw_add(t, r)
+        assert torch.equal(back, x + r)
+        gy = torch.randn(B, C, H, W, generator=g).cuda()
+        (back * gy).sum().backward()
+        assert torch.equal(x.grad, gy) and torch.equal(r.grad, gy)
