@@ -151,7 +151,8 @@ int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias,
  * skp_conv3x3_filter_f32: one-off transform of a frozen weight w [Cout,Cin,3,3] into the kernel's operand order
  *   U [16][Cin/8][2][Cout][4] (16*Cin*Cout floats; Cin % 8 == 0).  flip_transpose = 1 builds the filter of the
  *   backward-data convolution instead: pass the SAME w [Cw_out,Cw_in,3,3] with Cout = Cw_in, Cin = Cw_out.
- * skp_conv3x3_f32: y [B,Cout,H,W] = conv(x [B,Cin,H,W]) (+ bias[Cout] if non-NULL).  Cout % 32 == 0;
+ * skp_conv3x3_f32: y [B,Cout,H,W] = conv(x [B,Cin,H,W]) (+ bias[Cout]) (+ residual [B,Cout,H,W]), both optional
+ *   (NULL); the residual is the ResnetBlock2D shortcut, added in the epilogue instead of a separate pass.  Cout % 32 == 0;
  *   variant 0 = auto, 1 = workgroup of 128 channels x 32 tiles (Cin % 32 == 0), 2 = 64 channels x 64 tiles
  *   (Cin % 16 == 0).  x and U must each be < 2 GiB (32-bit buffer offsets), else SKP_E_RANGE.
  *   Layers with too few workgroups for the 256 CUs are split over input channels (deterministic: partial outputs in
@@ -159,8 +160,8 @@ int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias,
  *   split).  workspace NULL forces the unsplit launch. */
 int skp_conv3x3_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream);
 int64_t skp_conv3x3_workspace(int B, int Cin, int Cout, int H, int W, int variant);
-int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin, int Cout,
-                    int H, int W, int variant, void* stream);
+int skp_conv3x3_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
+                    int B, int Cin, int Cout, int H, int W, int variant, void* stream);
 
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0

@@ -64,6 +64,7 @@ __device__ __forceinline__ float skp_block_sum_256(float v, float* red) {
 // an offset with bit 31 set is out of range for the descriptor and returns 0 (used for the zero padding).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ float skp_buf_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x2 skp_buf_load_f32x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ f32x4 skp_buf_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ __forceinline__ i32x4 skp_make_rsrc(const void* p, unsigned bytes) {
     const unsigned long long v = (unsigned long long)p;
@@ -74,4 +75,6 @@ __device__ __forceinline__ i32x4 skp_make_rsrc(const void* p, unsigned bytes) {
     r[3] = 0x00020000;
     return r;
 }
-#define SKP_OOB ((int)0x80000000)
+__device__ void skp_buf_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void skp_buf_store_f32x2(f32x2 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+#define SKP_OOB ((int)0x80000000)      /* loads return 0, stores are dropped */

@@ -14,6 +14,7 @@
 // (double buffered, 2 x 64 KB), already in MFMA operand order; the filter side U is transformed once per
 // layer (weights are frozen) into the same operand order and streamed from L2 with 512-byte coalesced
 // b128 loads.  Tiles sit on the lane axis, so the 2x2 outputs leave as coalesced float2 rows.
+#include <type_traits>
 #include "skp_common.h"
 
 namespace {
@@ -67,10 +68,11 @@ struct WinoArgs {
     const float* x;
     const float* U;
     const float* bias;      // may be null
+    const float* res;       // residual added to the output (same shape), may be null
     float* y;
     int B, Cin, Cout, H, W;
     int tilesX, tilesPerImg, nTiles;
-    unsigned x_bytes, u_bytes;
+    unsigned x_bytes, u_bytes, y_bytes;
     int steps;              // channel stages per workgroup (= Cin / KC / splits)
     size_t y_split_stride;  // elements between the partial outputs of consecutive splits (blockIdx.z)
 };
@@ -88,7 +90,7 @@ struct PatchIdx {
     int off[4][4];          // byte offset of (row i, col j) of channel quad 0 of this tile's image, or SKP_OOB
 };
 
-template <int CB, int TB>
+template <int CB, int TB, bool VEC>     // VEC: W even -> 2x2 outputs / residuals move as aligned float2 rows
 __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
     using S = WinoShape<CB, TB>;
     extern __shared__ f32x4 vst[];                   // [2][16][NC8][2][NTILE]
@@ -176,6 +178,19 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
     const int uvo = (hi * a.Cout + co_l) * 16;
     const int u_c8 = 2 * a.Cout * 16, u_p = C8 * u_c8;
 
+    // ---- output role of this lane (tile = lane, 16 output channels in registers), needed early for the residual ----
+    const int tgo = tile0 + tbi * 32 + li;
+    const bool out_ok = wave_active && tgo < a.nTiles;
+    const int tgoc = out_ok ? tgo : 0;
+    const int ob = tgoc / a.tilesPerImg, orem = tgoc - ob * a.tilesPerImg;
+    const int oty = orem / a.tilesX, otx = orem - oty * a.tilesX;
+    const int oy = 2 * oty, ox = 2 * otx;
+    const bool row1 = oy + 1 < a.H, col1 = ox + 1 < a.W;
+    const int o_base = (ob * a.Cout * a.H + oy) * a.W + ox;          // + co*H*W
+    // residual and bias ride in registers loaded under the last stage's MFMAs; without them every load is out of range -> 0
+    const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
+    const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+
     load_patch(cin_begin);
     transform_store(0);
     // U operands travel through a ring of UD+1 positions: the position needed UD products from now is requested
@@ -188,8 +203,11 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
 #pragma unroll
         for (int c = 0; c < S::NC8; ++c) ua[q][c] = skp_buf_load_f32x4(urs, uvo, (cin_begin >> 3) * u_c8 + q * u_p + c * u_c8, 0);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
+    // One channel stage.  MODE 0: a further stage follows (its patch loads ride along); 1: last stage; 2: last stage
+    // with the residual's 2x2 values riding in the (now free) patch registers.  Three straight-line copies of the
+    // position loop instead of wave-uniform branches inside it (and no branch around the accumulators either).
+    auto run_stage = [&](int s, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
         // inactive waves (n0 >= Cout) run the same products on clamped rows: no divergent region around the accumulators
         const f32x4* vb = vst + (s & 1) * S::STAGE_F4 + (size_t)hi * S::NTILE + tbi * 32 + li;
         const int ub = ((cin_begin >> 3) + s * S::NC8) * u_c8;
@@ -198,17 +216,32 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
         for (int c = 0; c < S::NC8; ++c) va[0][c] = vb[(size_t)c * (2 * S::NTILE)];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            {   // U for position p+UD (wrapping into the next stage; past the last stage the loads are out of range -> 0)
+            if (MODE == 0 || p + UD < 16) {   // U for position p+UD (wrapping into the next stage)
                 const int q = p + UD;
                 const int uo = q < 16 ? ub + q * u_p : ub + S::NC8 * u_c8 + (q - 16) * u_p;
 #pragma unroll
                 for (int c = 0; c < S::NC8; ++c) ua[q % (UD + 1)][c] = skp_buf_load_f32x4(urs, uvo, uo + c * u_c8, 0);
             }
-            {   // this position's quarter-channel of the next stage's patches (unused garbage after the last stage)
+            if (MODE == 0) {                  // this position's quarter-channel of the next stage's patches
                 const int m = p >> 2, i = p & 3;
                 const int so = (cin_begin + (s + 1) * S::KC + m) * HW * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) d[m][i][j] = skp_buf_load_f32(xrs, pi.off[i][j], so, 0);
+            } else if (MODE == 2) {           // the 2x2 residual values of output-channel register p
+                const int co = n0 + (p & 3) + 8 * (p >> 2) + 4 * hi;
+                const bool ok = out_ok && co < a.Cout;
+                const int vo = (o_base + co * HW) * 4;
+                if (VEC) {
+                    const f32x2 r0 = skp_buf_load_f32x2(rrs, ok ? vo : SKP_OOB, 0, 0);
+                    const f32x2 r1 = skp_buf_load_f32x2(rrs, ok && row1 ? vo + a.W * 4 : SKP_OOB, 0, 0);
+                    d[p >> 2][p & 3][0] = r0[0]; d[p >> 2][p & 3][1] = r0[1];
+                    d[p >> 2][p & 3][2] = r1[0]; d[p >> 2][p & 3][3] = r1[1];
+                } else {
+                    d[p >> 2][p & 3][0] = skp_buf_load_f32(rrs, ok ? vo : SKP_OOB, 0, 0);
+                    d[p >> 2][p & 3][1] = skp_buf_load_f32(rrs, ok && col1 ? vo + 4 : SKP_OOB, 0, 0);
+                    d[p >> 2][p & 3][2] = skp_buf_load_f32(rrs, ok && row1 ? vo + a.W * 4 : SKP_OOB, 0, 0);
+                    d[p >> 2][p & 3][3] = skp_buf_load_f32(rrs, ok && row1 && col1 ? vo + a.W * 4 + 4 : SKP_OOB, 0, 0);
+                }
             }
             if (p + 1 < 16) {
 #pragma unroll
@@ -221,50 +254,54 @@ __global__ __launch_bounds__(256, 1) void skp_wino_conv_kernel(WinoArgs a) {
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p % (UD + 1)][c][m], va[p & 1][c][m], acc[p], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) transform_store((s + 1) & 1);
+    };
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        run_stage(s, std::integral_constant<int, 0>{});
+        transform_store((s + 1) & 1);
         __syncthreads();
     }
-    if (!wave_active) return;
-
-    // ---- output transform (in-lane) + store: lane = tile, register r = output channel ----
-    const int tg = tile0 + tbi * 32 + li;
-    if (tg >= a.nTiles) return;
-    const int b = tg / a.tilesPerImg, rem = tg - b * a.tilesPerImg;
-    const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
-    const int oy = 2 * ty, ox = 2 * tx;
-    const bool row1 = oy + 1 < a.H, col1 = ox + 1 < a.W;
-    const bool vec = col1 && ((a.W & 1) == 0);
+    float bvs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (co >= a.Cout) continue;
+        bvs[r] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
+    }
+    run_stage(nsteps - 1, std::integral_constant<int, 2>{});       // without a residual its loads are out of range -> 0
+
+    // ---- output transform (in-lane) + store: lane = tile, register r = output channel.  No branches: invalid
+    //      lanes / channels / rows store to an out-of-range buffer offset, which the hardware drops. ----
+    const i32x4 yrs = skp_make_rsrc(a.y + blockIdx.z * a.y_split_stride, a.y_bytes);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = n0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const bool ok = out_ok && co < a.Cout;
         float sr[4], dr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             sr[i] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
             dr[i] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
         }
-        const float bv = a.bias ? a.bias[co] : 0.f;
-        const float y00 = sr[0] + sr[1] + sr[2] + bv, y01 = dr[0] + dr[1] + dr[2] + bv;
-        const float y10 = sr[1] - sr[2] - sr[3] + bv, y11 = dr[1] - dr[2] - dr[3] + bv;
-        float* yp = a.y + blockIdx.z * a.y_split_stride + ((size_t)(b * a.Cout + co) * a.H + oy) * a.W + ox;
-        if (vec) {
-            *(f32x2*)yp = f32x2{y00, y01};
-            if (row1) *(f32x2*)(yp + a.W) = f32x2{y10, y11};
+        const float bv = bvs[r];
+        const float y00 = sr[0] + sr[1] + sr[2] + bv + d[r >> 2][r & 3][0], y01 = dr[0] + dr[1] + dr[2] + bv + d[r >> 2][r & 3][1];
+        const float y10 = sr[1] - sr[2] - sr[3] + bv + d[r >> 2][r & 3][2], y11 = dr[1] - dr[2] - dr[3] + bv + d[r >> 2][r & 3][3];
+        const int vo = (o_base + co * HW) * 4;
+        if (VEC) {
+            skp_buf_store_f32x2(f32x2{y00, y01}, yrs, ok ? vo : SKP_OOB, 0, 0);
+            skp_buf_store_f32x2(f32x2{y10, y11}, yrs, ok && row1 ? vo + a.W * 4 : SKP_OOB, 0, 0);
         } else {
-            yp[0] = y00;
-            if (col1) yp[1] = y01;
-            if (row1) {
-                yp[a.W] = y10;
-                if (col1) yp[a.W + 1] = y11;
-            }
+            skp_buf_store_f32(y00, yrs, ok ? vo : SKP_OOB, 0, 0);
+            skp_buf_store_f32(y01, yrs, ok && col1 ? vo + 4 : SKP_OOB, 0, 0);
+            skp_buf_store_f32(y10, yrs, ok && row1 ? vo + a.W * 4 : SKP_OOB, 0, 0);
+            skp_buf_store_f32(y11, yrs, ok && row1 && col1 ? vo + a.W * 4 + 4 : SKP_OOB, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);       // one output channel at a time: keeps the accumulator reads from piling up in VGPRs
     }
 }
 
 // y[i] = sum_z part[z][i] (+ bias[channel]) in fixed order: the deterministic tail of the split-K launches
-__global__ void skp_wino_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
-                                       size_t n4, size_t stride, int splits, int HW4, int Cout) {
+__global__ void skp_wino_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                       const float* __restrict__ res, float* __restrict__ y, size_t n4, size_t stride,
+                                       int splits, int HW4, int Cout) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     f32x4 acc = ((const f32x4*)part)[i];
@@ -273,22 +310,23 @@ __global__ void skp_wino_reduce_kernel(const float* __restrict__ part, const flo
         const float bv = bias[(i / HW4) % Cout];
         acc += f32x4{bv, bv, bv, bv};
     }
+    if (res) acc += ((const f32x4*)res)[i];
     ((f32x4*)y)[i] = acc;
 }
 
-template <int CB, int TB>
-int launch_wino(const WinoArgs& a, int splits, hipStream_t st) {
+template <int CB, int TB, bool VEC>
+int launch_wino_v(const WinoArgs& a, int splits, hipStream_t st) {
     using S = WinoShape<CB, TB>;
     const size_t lds = (size_t)2 * S::STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB>,
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino_conv_kernel<CB, TB, VEC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid((a.nTiles + S::NTILE - 1) / S::NTILE, (a.Cout + 32 * CB - 1) / (32 * CB), splits);
-    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((skp_wino_conv_kernel<CB, TB, VEC>), grid, dim3(256), lds, st, a);
     return skp_launch_status();
 }
 
@@ -301,6 +339,11 @@ extern "C" int skp_conv3x3_filter_f32(const void* w, void* U, int Cout, int Cin,
     hipLaunchKernelGGL(skp_wino_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float*)w, (float*)U, Cout, Cin, flip_transpose);
     return skp_launch_status();
+}
+
+template <int CB, int TB>
+int launch_wino(const WinoArgs& a, int splits, hipStream_t st) {
+    return (a.W & 1) ? launch_wino_v<CB, TB, false>(a, splits, st) : launch_wino_v<CB, TB, true>(a, splits, st);
 }
 
 // Split-K choice: fill the 256 CUs (one workgroup each: 512 registers per lane, 128 KB LDS).  Cost model in
@@ -335,8 +378,8 @@ extern "C" int64_t skp_conv3x3_workspace(int B, int Cin, int Cout, int H, int W,
     return S > 1 ? (int64_t)S * B * Cout * H * W * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin,
-                               int Cout, int H, int W, int variant, void* stream) {
+extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
+                               int B, int Cin, int Cout, int H, int W, int variant, void* stream) {
     if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return SKP_E_BADARG;
     if ((Cout & 31) != 0) return SKP_E_RANGE;
     int v;
@@ -352,11 +395,15 @@ extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, v
     const unsigned long long xb = (unsigned long long)B * Cin * H * W * 4, ub = (unsigned long long)16 * Cin * Cout * 4;
     if (xb >= 0x80000000ull || ub >= 0x80000000ull) return SKP_E_RANGE;     // 32-bit buffer offsets
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub;
+    const unsigned long long yb = (unsigned long long)B * Cout * H * W * 4;
+    if (yb >= 0x80000000ull) return SKP_E_RANGE;
+    a.y_bytes = (unsigned)yb;
     const size_t out_elems = (size_t)B * Cout * H * W;
     a.steps = Cin / (v == 2 ? 16 : 32) / S;
     a.y_split_stride = out_elems;
     a.y = S > 1 ? (float*)workspace : (float*)y;
     a.bias = S > 1 ? nullptr : (const float*)bias;
+    a.res = S > 1 ? nullptr : (const float*)residual;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (v == 1) rc = launch_wino<4, 1>(a, S, st);
@@ -365,6 +412,6 @@ extern "C" int skp_conv3x3_f32(const void* x, const void* U, const void* bias, v
     if ((H * W) % 4) return SKP_E_RANGE;                    // (wino_plan only splits when the reduce pass applies)
     const size_t n4 = out_elems / 4;
     hipLaunchKernelGGL(skp_wino_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
-                       (const float*)bias, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
+                       (const float*)bias, (const float*)residual, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
     return skp_launch_status();
 }

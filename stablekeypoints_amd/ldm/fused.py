@@ -31,8 +31,7 @@ def _resnet_forward(m: ResnetBlock2D):
         h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
         if m.conv_shortcut is not None:
             x = m.conv_shortcut(x)
-        h = ops.conv3x3_auto(h, m.conv2.weight)                          # bias added together with the residual
-        return ops.add_bias_residual(x, h, m.conv2.bias)
+        return ops.conv3x3_auto(h, m.conv2.weight, m.conv2.bias, residual=x)   # bias + shortcut in the conv epilogue
     return forward
 
 

@@ -480,14 +480,15 @@ def _wino_filters(weight, backward):
     return U
 
 
-def _conv3x3_raw(x, U, bias, cout, variant=0, split=True):
+def _conv3x3_raw(x, U, bias, cout, variant=0, split=True, residual=None):
     B, ci, H, W = x.shape
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     nbytes = N.lib().skp_conv3x3_workspace(B, ci, cout, H, W, int(variant)) if split else 0
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     N.check(N.lib().skp_conv3x3_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                    y.data_ptr(), ws.data_ptr() if ws is not None else None, B, ci, cout, H, W,
-                                    int(variant), _stream()), "skp_conv3x3_f32")
+                                    residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                    ws.data_ptr() if ws is not None else None, B, ci, cout, H, W, int(variant), _stream()),
+            "skp_conv3x3_f32")
     return y
 
 
@@ -501,14 +502,16 @@ def conv3x3_wanted(x_shape, w_shape):
 
 
 class Conv3x3Fn(torch.autograd.Function):
-    """y = conv2d(x, weight, bias, stride 1, padding 1) with frozen weight/bias; dx is the same kernel run with the
-    rotated, transposed filter."""
+    """y = conv2d(x, weight, bias, stride 1, padding 1) (+ residual) with frozen weight/bias; dx is the same kernel
+    run with the rotated, transposed filter; the residual's gradient is dy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual=None):
         x = _dev(x, "x")
         ctx.weight = weight
-        return _conv3x3_raw(x, _wino_filters(weight, False), bias, weight.shape[0])
+        if residual is not None:
+            residual = _dev(residual, "residual")
+        return _conv3x3_raw(x, _wino_filters(weight, False), bias, weight.shape[0], residual=residual)
 
     @staticmethod
     def backward(ctx, dy):
@@ -520,20 +523,26 @@ class Conv3x3Fn(torch.autograd.Function):
                 dx = _conv3x3_raw(_dev(dy, "dy"), _wino_filters(w, True), None, ci)
             else:       # too few workgroups for this kernel: library backward-data
                 dx = torch.nn.grad.conv2d_input((dy.shape[0], ci, dy.shape[2], dy.shape[3]), w, dy, padding=1)
-        return dx, None, None
+        return dx, None, None, (dy if ctx.needs_input_grad[3] else None)
 
 
-def conv3x3(x, weight, bias=None):
+def conv3x3(x, weight, bias=None, residual=None):
     if not conv3x3_supported(x.shape, weight.shape):
         raise ValueError(f"conv3x3: unsupported shape x {tuple(x.shape)} w {tuple(weight.shape)}")
-    return Conv3x3Fn.apply(x, weight, bias)
+    return Conv3x3Fn.apply(x, weight, bias, residual)
 
 
-def conv3x3_auto(x, weight, bias=None):
-    """The frozen blocks' 3x3 convolution: Winograd kernel where it is wanted, library convolution otherwise."""
+def conv3x3_auto(x, weight, bias=None, residual=None):
+    """The frozen blocks' 3x3 convolution (+ bias + residual): Winograd kernel where it is wanted, library
+    convolution (and the fused bias+residual pass) otherwise."""
     if x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
-        return Conv3x3Fn.apply(x, weight, bias)
-    return torch.nn.functional.conv2d(x, weight, bias, padding=1)
+        return Conv3x3Fn.apply(x, weight, bias, residual)
+    if residual is None:
+        return torch.nn.functional.conv2d(x, weight, bias, padding=1)
+    y = torch.nn.functional.conv2d(x, weight, None, padding=1)
+    if bias is not None and y.is_cuda and y.dtype == torch.float32 and (y.shape[2] * y.shape[3]) % 4 == 0:
+        return add_bias_residual(residual, y, bias)
+    return (y + bias[None, :, None, None] if bias is not None else y) + residual
 
 
 class GEGLUFn(torch.autograd.Function):

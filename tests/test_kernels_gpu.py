@@ -407,6 +407,12 @@ def test_winograd_conv3x3_fwd_bwd_vs_fp64(ops, B, ci, co, H, W, bias):
     torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
     # determinism
     assert torch.equal(ops.conv3x3(xg.detach(), wg, bg), y.detach())
+    # residual (ResnetBlock2D shortcut) added in the epilogue; its gradient is dy
+    res = torch.randn(B, co, H, W, generator=g).cuda().requires_grad_(True)
+    yr = ops.conv3x3(xg.detach(), wg, bg, res)
+    torch.testing.assert_close(yr.detach(), y.detach() + res.detach(), rtol=1e-6, atol=1e-6)
+    (yr * gy.cuda()).sum().backward()
+    assert torch.equal(res.grad, gy.cuda())
 
 
 def test_geglu_and_layout_kernels(ops):
