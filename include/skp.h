@@ -163,6 +163,15 @@ int64_t skp_conv3x3_workspace(int B, int Cin, int Cout, int H, int W, int varian
 int skp_conv3x3_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
                     int B, int Cin, int Cout, int H, int W, int variant, void* stream);
 
+/* The same convolution as Winograd F(4x4,3x3) (4x fewer multiplies than direct; skp_conv_wino4.hip) for H % 4 == 0,
+ * W % 4 == 0, Cin % 16 == 0, Cout % 16 == 0.  U [36][Cin/16][4][Cout][4] = 36*Cin*Cout floats from
+ * skp_conv3x3_f4_filter_f32 (same flip_transpose convention as skp_conv3x3_filter_f32).  fp32 throughout; the larger
+ * transform costs ~1 decimal digit (relative error ~3e-6 of the output maximum instead of ~3e-7). */
+int skp_conv3x3_f4_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream);
+int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
+                       int B, int Cin, int Cout, int H, int W, void* stream);
+
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0
  * _bwd writes dp [rows, 2*inner] = d loss / d p given dy [rows, inner]. */

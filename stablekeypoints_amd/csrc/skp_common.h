@@ -77,4 +77,5 @@ __device__ __forceinline__ i32x4 skp_make_rsrc(const void* p, unsigned bytes) {
 }
 __device__ void skp_buf_store_f32(float v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ void skp_buf_store_f32x2(f32x2 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void skp_buf_store_f32x4(f32x4 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 #define SKP_OOB ((int)0x80000000)      /* loads return 0, stores are dropped */

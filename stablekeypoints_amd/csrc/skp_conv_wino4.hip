@@ -1,0 +1,367 @@
+// 3x3 / stride 1 / pad 1 convolution as Winograd F(4x4,3x3) on the fp32 matrix cores, for layers whose height and
+// width are multiples of 4 (all VAE-encoder and UNet resolutions of the 512^2 path): 36 multiplies per 4x4 output
+// tile and channel pair, i.e. 4x fewer than the direct form (F(2x2,3x3) in skp_conv_wino.hip: 2.25x).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          6x6 transform domain, interpolation points 0, +-1, +-2, inf
+//
+// Work split (v_mfma_f32_16x16x4_f32): a wave owns 16 output channels x 32 tiles (two 16-tile column blocks) x all
+// 36 positions = 72 accumulator tiles of 4 registers (288 of the 512 registers of its SIMD), so the output transform
+// stays in-lane.  A workgroup = 4 waves = 64 output channels on the same 32 tiles; it transforms the 32 x 16-channel
+// input patches of a stage into LDS once (double buffered, 2 x 72 KB) in MFMA operand order.  The transformed filter
+// is streamed from L2 through a 12-position register ring (VMEM returns in order: everything queued behind a patch
+// load inherits its HBM latency, so the ring has to cover it).  The patch loads of the next stage are issued in the
+// first positions of the MFMA loop and their 6x6 transform + LDS writes are spread over the last positions, so the
+// matrix pipe does not wait for the VALU work.  fp32 throughout; relative error ~3e-6 of the output maximum.
+#include <type_traits>
+#include "skp_common.h"
+
+namespace {
+
+// ---- filter transform: U'[p][ci/16][(ci%16)/4][co][ci%4] = (G g G^T)[p], p = 6*i + j ----------------------------
+__global__ void skp_wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int flip_t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    float g[3][3];
+    if (!flip_t) {
+        const float* p = w + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p[a * 3 + b];
+    } else {
+        const float* p = w + ((size_t)ci * Cout + co) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = p[(2 - a) * 3 + (2 - b)];
+    }
+    const float G[6][3] = {{0.25f, 0.f, 0.f},
+                           {-1.f / 6, -1.f / 6, -1.f / 6},
+                           {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6},
+                           {1.f / 24, -1.f / 12, 1.f / 6},
+                           {0.f, 0.f, 1.f}};
+    float t[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) t[i][b] = G[i][0] * g[0][b] + G[i][1] * g[1][b] + G[i][2] * g[2][b];
+    const int c16 = ci >> 4, kq = (ci >> 2) & 3, m = ci & 3;
+    const int C16 = Cin >> 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+            const int p = i * 6 + j;
+            U[((((size_t)p * C16 + c16) * 4 + kq) * Cout + co) * 4 + m] = u;
+        }
+}
+
+struct Wino4Args {
+    const float* x;
+    const float* U;
+    const float* bias;      // may be null
+    const float* res;       // may be null
+    float* y;
+    int B, Cin, Cout, H, W;
+    int tilesX, tilesPerImg, nTiles;
+    unsigned x_bytes, u_bytes, y_bytes;
+    int steps;              // 16-channel stages per workgroup
+    size_t y_split_stride;
+};
+
+constexpr int W4_STAGE_F4 = 36 * 4 * 32;          // f32x4 per stage: [36 positions][4 k-quads][32 tiles]
+constexpr int W4_RING = 12;                       // filter ring slots (divides 36); prefetch distance RING-1 positions
+
+// B^T applied to a 6-vector
+__device__ __forceinline__ void w4_in1d(const float (&d)[6], float (&t)[6]) {
+    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
+    const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// A^T applied to a 6-vector
+__device__ __forceinline__ void w4_out1d(const float (&m)[6], float (&y)[4]) {
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.f * d34;
+    y[2] = s12 + 4.f * s34;
+    y[3] = d12 + 8.f * d34 + m[5];
+}
+
+__global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
+    extern __shared__ f32x4 vst[];                   // [2][36][4][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int tile0 = blockIdx.x * 32;
+    const int n0 = (blockIdx.y * 4 + wave) * 16;
+    const int HW = a.H * a.W;
+    const int nsteps = a.steps;
+    const int cin_begin = blockIdx.z * nsteps * 16;
+
+    // ---- transform role: the 6x6 patches of 2 consecutive channels of one tile ----
+    const int tl = tid & 31, cp = tid >> 5;
+    int roff[6];                                     // byte offset of (row i, column 4*tx) for channel pair 0, or SKP_OOB
+    bool lok, rok;
+    {
+        const int tg = tile0 + tl;
+        const bool tv = tg < a.nTiles;
+        const int tgc = tv ? tg : 0;
+        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        const int base = (b * a.Cin + 2 * cp) * HW + 4 * tx;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int r = 4 * ty - 1 + i;
+            roff[i] = (tv && r >= 0 && r < a.H) ? (base + r * a.W) * 4 : SKP_OOB;
+        }
+        lok = tx > 0;
+        rok = tx + 1 < a.tilesX;
+    }
+    const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
+    const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
+    float d[2][6][6];                                // [channel][row][col]
+    auto load_row = [&](int cin0, int e, int i) {    // one patch row: left scalar, 4 aligned columns, right scalar
+        const int so = (cin0 + e) * HW * 4;
+        const f32x4 mid = skp_buf_load_f32x4(xrs, roff[i], so, 0);
+        d[e][i][0] = skp_buf_load_f32(xrs, lok ? roff[i] - 4 : SKP_OOB, so, 0);
+        d[e][i][1] = mid[0]; d[e][i][2] = mid[1]; d[e][i][3] = mid[2]; d[e][i][4] = mid[3];
+        d[e][i][5] = skp_buf_load_f32(xrs, rok ? roff[i] + 16 : SKP_OOB, so, 0);
+    };
+    auto col_pass = [&](int j) {                     // d[:, :, j] <- B^T d[:, :, j]   (vertical pass, both channels)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float v[6], t[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = d[e][i][j];
+            w4_in1d(v, t);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[e][i][j] = t[i];
+        }
+    };
+    auto row_pass_store = [&](int buf, int i) {      // V[i][:] = (row i) B, both channels, written as float2 (channels 2cp, 2cp+1)
+        float t0[6], t1[6];
+        w4_in1d(d[0][i], t0);
+        w4_in1d(d[1][i], t1);
+        float* dst = (float*)(vst + buf * W4_STAGE_F4) + (((i * 6) * 4 + (cp >> 1)) * 32 + tl) * 4 + 2 * (cp & 1);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *(f32x2*)(dst + j * (4 * 32 * 4)) = f32x2{t0[j], t1[j]};
+    };
+
+    f32x4 acc[36][2];
+#pragma unroll
+    for (int p = 0; p < 36; ++p)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int C16 = a.Cin >> 4;
+    const int co_l = min(n0 + i16, a.Cout - 1);
+    const int uvo = (kq * a.Cout + co_l) * 16;
+    const int u_c16 = 4 * a.Cout * 16, u_p = C16 * u_c16;
+
+    // ---- output role (lane = tile within a 16-block, registers = 4 output channels) ----
+    int o_base[2];
+    bool t_ok[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tg = tile0 + tb * 16 + i16;
+        t_ok[tb] = tg < a.nTiles;
+        const int tgc = t_ok[tb] ? tg : 0;
+        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        o_base[tb] = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
+    }
+
+    // prologue: stage 0 patches, first ring slots
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { load_row(cin_begin, 0, i); load_row(cin_begin, 1, i); }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) col_pass(j);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) row_pass_store(0, i);
+    f32x4 ua[W4_RING];
+#pragma unroll
+    for (int q = 0; q < W4_RING - 1; ++q) ua[q] = skp_buf_load_f32x4(urs, uvo, (cin_begin >> 4) * u_c16 + q * u_p, 0);
+    __syncthreads();
+
+    // MODE 0: a further stage follows (its patch loads + transform ride along); MODE 1: last stage
+    auto run_stage = [&](int s, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const f32x4* vb = vst + (s & 1) * W4_STAGE_F4 + kq * 32 + i16;
+        const int ub = ((cin_begin >> 4) + s) * u_c16;
+        f32x4 va[2][2];
+        va[0][0] = vb[0];
+        va[0][1] = vb[16];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) {
+            {   // filter operand for position p + RING-1 (wrapping into the next stage)
+                constexpr int D = W4_RING - 1;
+                const int q = p + D;
+                if (MODE == 0 || q < 36) {
+                    const int uo = q < 36 ? ub + q * u_p : ub + u_c16 + (q - 36) * u_p;
+                    ua[q % W4_RING] = skp_buf_load_f32x4(urs, uvo, uo, 0);
+                }
+            }
+            if (MODE == 0) {
+                if (p < 6) {                         // next stage's patch rows, both channels
+                    load_row(cin_begin + (s + 1) * 16, 0, p);
+                    load_row(cin_begin + (s + 1) * 16, 1, p);
+                } else if (p >= 24 && p < 30) {
+                    col_pass(p - 24);
+                } else if (p >= 30) {
+                    row_pass_store((s + 1) & 1, p - 30);
+                }
+            }
+            if (p + 1 < 36) {
+                va[(p + 1) & 1][0] = vb[(p + 1) * 128];
+                va[(p + 1) & 1][1] = vb[(p + 1) * 128 + 16];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4_RING][m], va[p & 1][tb][m], acc[p][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        run_stage(s, std::integral_constant<int, 0>{});
+        __syncthreads();
+    }
+    run_stage(nsteps - 1, std::integral_constant<int, 1>{});
+
+    // ---- output transform (in-lane) + store.  Branch-free: invalid tiles/channels store out of range (dropped). ----
+    const i32x4 yrs = skp_make_rsrc(a.y + blockIdx.z * a.y_split_stride, a.y_bytes);
+    const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
+    const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 4 * kq + r;
+        const float bv = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const bool ok = t_ok[tb] && co < a.Cout;
+            const int vo = (o_base[tb] + co * HW) * 4;
+            f32x4 rr[4];
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) rr[oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            float t[6][4];                           // T = M A : rows of the 6x6 tile -> 4 columns
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float m[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                w4_out1d(m, t[i]);
+            }
+#pragma unroll
+            for (int ox = 0; ox < 4; ++ox) {
+                float m[6], yv[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
+                w4_out1d(m, yv);
+#pragma unroll
+                for (int oy = 0; oy < 4; ++oy) rr[oy][ox] += yv[oy] + bv;
+            }
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// y = sum_z part[z] (+ bias[channel]) (+ res), fixed order
+__global__ void skp_wino4_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                        const float* __restrict__ res, float* __restrict__ y, size_t n4, size_t stride,
+                                        int splits, int HW4, int Cout) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = ((const f32x4*)part)[i];
+    for (int z = 1; z < splits; ++z) acc += ((const f32x4*)(part + z * stride))[i];
+    if (bias) {
+        const float bv = bias[(i / HW4) % Cout];
+        acc += f32x4{bv, bv, bv, bv};
+    }
+    if (res) acc += ((const f32x4*)res)[i];
+    ((f32x4*)y)[i] = acc;
+}
+
+int wino4_plan(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    if ((Cin % 16) || (Cout % 16) || (H % 4) || (W % 4)) return 0;
+    const int tiles = B * (H / 4) * (W / 4);
+    const int wgs = ((tiles + 31) / 32) * ((Cout + 63) / 64);
+    const int nsteps = Cin / 16;
+    const double out_bytes = (double)B * Cout * H * W * 4;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int S = 1; S <= 16; ++S) {
+        if (nsteps % S) continue;
+        const int rounds = (wgs * S + 255) / 256;
+        double cost = rounds * (nsteps / S + 2.0) * 3.9;       // ~2 stages of prologue + epilogue per workgroup
+        if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 4.0e6;
+        if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int skp_conv3x3_f4_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream) {
+    if (!w || !U || Cout <= 0 || Cin <= 0) return SKP_E_BADARG;
+    if (Cin & 15) return SKP_E_RANGE;
+    const int n = Cout * Cin;
+    hipLaunchKernelGGL(skp_wino4_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w,
+                       (float*)U, Cout, Cin, flip_transpose);
+    return skp_launch_status();
+}
+
+extern "C" int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int W) {
+    const int S = wino4_plan(B, Cin, Cout, H, W);
+    return S > 1 ? (int64_t)S * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y,
+                                  void* workspace, int B, int Cin, int Cout, int H, int W, void* stream) {
+    if (!x || !U || !y) return SKP_E_BADARG;
+    int S = wino4_plan(B, Cin, Cout, H, W);
+    if (S == 0) return (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) ? SKP_E_BADARG : SKP_E_RANGE;
+    if (!workspace) S = 1;
+    const unsigned long long xb = (unsigned long long)B * Cin * H * W * 4, ub = (unsigned long long)36 * Cin * Cout * 4,
+                             yb = (unsigned long long)B * Cout * H * W * 4;
+    if (xb >= 0x80000000ull || ub >= 0x80000000ull || yb >= 0x80000000ull) return SKP_E_RANGE;
+    Wino4Args a;
+    a.x = (const float*)x; a.U = (const float*)U;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.tilesX = W / 4;
+    a.tilesPerImg = a.tilesX * (H / 4);
+    a.nTiles = B * a.tilesPerImg;
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
+    a.steps = Cin / 16 / S;
+    const size_t out_elems = (size_t)B * Cout * H * W;
+    a.y_split_stride = out_elems;
+    a.y = S > 1 ? (float*)workspace : (float*)y;
+    a.bias = S > 1 ? nullptr : (const float*)bias;
+    a.res = S > 1 ? nullptr : (const float*)residual;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino4_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((a.nTiles + 31) / 32, (Cout + 63) / 64, S);
+    hipLaunchKernelGGL(skp_wino4_conv_kernel, grid, dim3(256), lds, st, a);
+    int rc = skp_launch_status();
+    if (rc || S == 1) return rc;
+    const size_t n4 = out_elems / 4;
+    hipLaunchKernelGGL(skp_wino4_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                       (const float*)bias, (const float*)residual, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
+    return skp_launch_status();
+}

@@ -6,6 +6,7 @@ stream.  No op has an eager/CPU fallback: a non-CUDA tensor raises.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence, Tuple
 
 import torch
@@ -492,13 +493,60 @@ def _conv3x3_raw(x, U, bias, cout, variant=0, split=True, residual=None):
     return y
 
 
+def _wino4_filters(weight, backward):
+    """F(4x4,3x3) transformed filter of a frozen weight (36*Cin*Cout floats), built once and kept resident."""
+    key = "_skp_wino4_bwd" if backward else "_skp_wino4_fwd"
+    hit = getattr(weight, key, None)
+    if hit is not None and hit[0] == weight._version and hit[1].device == weight.device:
+        return hit[1]
+    w = _dev(weight.detach(), "weight")
+    co, ci = w.shape[:2]
+    U = torch.empty(36 * co * ci, device=w.device, dtype=torch.float32)
+    if backward:
+        N.check(N.lib().skp_conv3x3_f4_filter_f32(w.data_ptr(), U.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_f4_filter_f32")
+    else:
+        N.check(N.lib().skp_conv3x3_f4_filter_f32(w.data_ptr(), U.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_f4_filter_f32")
+    setattr(weight, key, (weight._version, U))
+    return U
+
+
+def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None):
+    B, ci, H, W = x.shape
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    nbytes = N.lib().skp_conv3x3_f4_workspace(B, ci, cout, H, W) if split else 0
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    N.check(N.lib().skp_conv3x3_f4_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                       ws.data_ptr() if ws is not None else None, B, ci, cout, H, W, _stream()),
+            "skp_conv3x3_f4_f32")
+    return y
+
+
+# "f4": Winograd F(4x4,3x3) where the shape allows (H, W % 4 == 0), F(2x2,3x3) otherwise; "f2": F(2x2,3x3) only;
+# "lib": library convolution everywhere (A/B runs and the consistency test).  Default f4.
+CONV3X3_MODE = os.environ.get("SKP_CONV3X3", "f4")
+
+
+def conv3x3_f4_ok(x_shape, w_shape):
+    b, _, h, w = (int(v) for v in x_shape)
+    return (CONV3X3_MODE == "f4" and h % 4 == 0 and w % 4 == 0 and int(w_shape[0]) % 16 == 0 and int(w_shape[1]) % 16 == 0
+            and b * (h // 4) * (w // 4) >= 32 and 36 * int(w_shape[0]) * int(w_shape[1]) * 4 < 2 ** 31)
+
+
 def conv3x3_wanted(x_shape, w_shape):
-    """Supported AND enough 2x2 tiles to fill the 32-tile MFMA column blocks (layers with few workgroups are split
-    over input channels inside the library call, so the channel counts do not matter here)."""
-    if not conv3x3_supported(x_shape, w_shape):
+    """Supported AND enough tiles to fill the MFMA column blocks (layers with few workgroups are split over input
+    channels inside the library call, so the channel counts do not matter here)."""
+    if CONV3X3_MODE == "lib" or not conv3x3_supported(x_shape, w_shape):
         return False
     b, _, h, w = (int(v) for v in x_shape)
-    return b * ((h + 1) // 2) * ((w + 1) // 2) >= 128
+    return conv3x3_f4_ok(x_shape, w_shape) or b * ((h + 1) // 2) * ((w + 1) // 2) >= 128
+
+
+def _conv3x3_run(x, weight, backward, bias, residual, cout):
+    w_shape = (weight.shape[1], weight.shape[0], 3, 3) if backward else weight.shape
+    if conv3x3_f4_ok(x.shape, w_shape):
+        return _conv3x3_f4_raw(x, _wino4_filters(weight, backward), bias, cout, residual=residual)
+    return _conv3x3_raw(x, _wino_filters(weight, backward), bias, cout, residual=residual)
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -511,7 +559,7 @@ class Conv3x3Fn(torch.autograd.Function):
         ctx.weight = weight
         if residual is not None:
             residual = _dev(residual, "residual")
-        return _conv3x3_raw(x, _wino_filters(weight, False), bias, weight.shape[0], residual=residual)
+        return _conv3x3_run(x, weight, False, bias, residual, weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
@@ -520,8 +568,8 @@ class Conv3x3Fn(torch.autograd.Function):
             w = ctx.weight
             co, ci = w.shape[:2]
             if conv3x3_wanted(dy.shape, (ci, co, 3, 3)):
-                dx = _conv3x3_raw(_dev(dy, "dy"), _wino_filters(w, True), None, ci)
-            else:       # too few workgroups for this kernel: library backward-data
+                dx = _conv3x3_run(_dev(dy, "dy"), w, True, None, None, ci)
+            else:       # too few tiles for these kernels: library backward-data
                 dx = torch.nn.grad.conv2d_input((dy.shape[0], ci, dy.shape[2], dy.shape[3]), w, dy, padding=1)
         return dx, None, None, (dy if ctx.needs_input_grad[3] else None)
 

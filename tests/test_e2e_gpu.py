@@ -183,3 +183,41 @@ def test_bench_two_ranks_one_gpu_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["scaling"] == "weak" and d["steps"] == 2
+
+
+def test_sd_shapes_maps_with_winograd_convs_match_library_convs():
+    """SD-1.5 architecture at 256^2 (BASELINE configs[0] shapes): the [T,R,R] maps and the context gradient computed
+    with the Winograd conv3x3 kernels (F(4x4,3x3) / F(2x2,3x3)) against the same step with the library convolutions.
+    Tolerance: maps rtol 1e-3 (north_star)."""
+    from stablekeypoints_amd import ops, ptp_utils
+    from stablekeypoints_amd.optimize_token import load_ldm
+    ldm, controllers, n = load_ldm("cuda:0", "sd15", feature_upsample_res=64)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(2, 3, 256, 256, generator=g).to(dev)
+    noise = torch.randn(2, 4, 32, 32, generator=g).to(dev)
+    # context scaled so that the token softmax is clearly non-uniform (max/mean ~3.5) while the random-weight network is
+    # still well conditioned: at this scale two runs of the LIBRARY path differ by ~1e-5 (its own nondeterminism), the
+    # Winograd kernels by 1-2e-5; at 8x this scale the library path already disagrees with itself by 30 %.
+    ctx0 = torch.randn(1, 77, 768, generator=g) * 5.0
+    out = {}
+    prev = ops.CONV3X3_MODE
+    try:
+        for mode in ("lib", "f4", "f2"):
+            ops.CONV3X3_MODE = mode
+            context = ctx0.clone().to(dev).requires_grad_(True)
+            maps = ptp_utils.run_and_find_attn(ldm, images, context, layers=[0, 1, 2, 3], noise_level=-1, from_where=["up_cross"],
+                                               upsample_res=64, device=dev, controllers=controllers, noise=noise)
+            m = maps if torch.is_tensor(maps) else torch.stack(list(maps))
+            (m * torch.linspace(0, 1, m.numel(), device=dev).reshape(m.shape)).sum().backward()
+            out[mode] = (m.detach().clone(), context.grad.detach().clone())
+    finally:
+        ops.CONV3X3_MODE = prev
+    ref_maps = out["lib"][0]
+    print("map max/mean", (ref_maps.max() / ref_maps.mean()).item(), "grad max", out["lib"][1].abs().max().item())
+    assert ref_maps.max() > 2.5 * ref_maps.mean()               # the comparison has teeth: maps are not uniform
+    for mode in ("f4", "f2"):
+        print(mode, "max rel map diff", ((out[mode][0] - ref_maps).abs() / ref_maps.abs().clamp_min(1e-6)).max().item())
+        torch.testing.assert_close(out[mode][0], out["lib"][0], rtol=1e-3, atol=1e-6)
+        gref = out["lib"][1]
+        torch.testing.assert_close(out[mode][1], gref, rtol=5e-3, atol=1e-3 * gref.abs().max().item())

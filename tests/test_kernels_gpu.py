@@ -379,7 +379,7 @@ def test_sd_shape_backward_is_deterministic_and_finite(ops):
 
 @pytest.mark.parametrize("B,ci,co,H,W,bias", [(2, 32, 32, 8, 8, True), (1, 64, 96, 7, 5, False), (3, 32, 160, 6, 10, True),
                                               (8, 128, 128, 64, 64, True), (2, 320, 320, 16, 16, False),
-                                              (1, 96, 64, 33, 17, True)])
+                                              (1, 96, 64, 33, 17, True), (3, 64, 96, 12, 20, True), (8, 1280, 640, 8, 8, False)])
 def test_winograd_conv3x3_fwd_bwd_vs_fp64(ops, B, ci, co, H, W, bias):
     """3x3/s1/p1 convolution of the frozen blocks (Winograd F(2x2,3x3) on fp32 MFMA) against fp64 conv2d: forward
     (+bias), and the input gradient through the same kernel with the rotated/transposed filter.  Both workgroup
@@ -395,22 +395,30 @@ def test_winograd_conv3x3_fwd_bwd_vs_fp64(ops, B, ci, co, H, W, bias):
     xg, wg = x.cuda().requires_grad_(True), w.cuda()
     bg = None if b is None else b.cuda()
     assert ops.conv3x3_supported(xg.shape, wg.shape)
-    y = ops.conv3x3(xg, wg, bg)
+    y = ops.conv3x3(xg, wg, bg)                            # F(4x4,3x3) or F(2x2,3x3) by shape
     tol = 2e-5 * ref.abs().max().item()
-    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=tol)
+    tol4 = 6e-5 * ref.abs().max().item()                   # F(4x4,3x3): ~1 digit less than F(2x2,3x3), see skp.h
+    torch.testing.assert_close(y.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=tol4)
+    if H % 4 == 0 and W % 4 == 0 and ci % 16 == 0 and co % 16 == 0:
+        y4 = ops._conv3x3_f4_raw(xg.detach(), ops._wino4_filters(wg, False), bg, co)
+        torch.testing.assert_close(y4.cpu().double(), ref.detach(), rtol=1e-4, atol=tol4)
+        y4n = ops._conv3x3_f4_raw(xg.detach(), ops._wino4_filters(wg, False), bg, co, split=False)
+        torch.testing.assert_close(y4n.cpu().double(), ref.detach(), rtol=1e-4, atol=tol4)
+        dx4 = ops._conv3x3_f4_raw(gy.cuda(), ops._wino4_filters(wg, True), None, ci)
+        torch.testing.assert_close(dx4.cpu().double(), xd.grad, rtol=1e-4, atol=6e-5 * xd.grad.abs().max().item())
     for variant in (1, 2):
         yv = ops._conv3x3_raw(xg.detach(), ops._wino_filters(wg, False), bg, co, variant)
         torch.testing.assert_close(yv.cpu().double(), ref.detach(), rtol=1e-4, atol=tol)
     dx = ops._conv3x3_raw(gy.cuda(), ops._wino_filters(wg, True), None, ci)
     torch.testing.assert_close(dx.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
     (y * gy.cuda()).sum().backward()                       # autograd path (kernel or library by size)
-    torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=2e-5 * xd.grad.abs().max().item())
+    torch.testing.assert_close(xg.grad.cpu().double(), xd.grad, rtol=1e-4, atol=6e-5 * xd.grad.abs().max().item())
     # determinism
     assert torch.equal(ops.conv3x3(xg.detach(), wg, bg), y.detach())
     # residual (ResnetBlock2D shortcut) added in the epilogue; its gradient is dy
     res = torch.randn(B, co, H, W, generator=g).cuda().requires_grad_(True)
     yr = ops.conv3x3(xg.detach(), wg, bg, res)
-    torch.testing.assert_close(yr.detach(), y.detach() + res.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(yr.detach(), y.detach() + res.detach(), rtol=1e-5, atol=1e-5)
     (yr * gy.cuda()).sum().backward()
     assert torch.equal(res.grad, gy.cuda())
 

@@ -49,6 +49,13 @@ def main():
                 err = ((y - ref).abs().max() / ref.abs().max()).item()
                 t = timeit(lambda: ops._conv3x3_raw(x, U, b, co, v, split))
                 line += f" v{v}{'s' if split else ' '} {t:6.2f} ms {fl / t:6.1f} TF/s-eq err {err:.1e} |"
+        if H % 4 == 0:
+            U4 = ops._wino4_filters(w, False)
+            y4 = ops._conv3x3_f4_raw(x, U4, b, co)
+            err4 = ((y4 - ref).abs().max() / ref.abs().max()).item()
+            t4 = timeit(lambda: ops._conv3x3_f4_raw(x, U4, b, co))
+            line += f" F4 {t4:6.2f} ms {fl / t4:6.1f} TF/s-eq err {err4:.1e} |"
+            del U4, y4
         # backward-data
         dy = torch.randn_like(ref)
         Ub = ops._wino_filters(w, True)
