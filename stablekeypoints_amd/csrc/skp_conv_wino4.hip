@@ -240,17 +240,36 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     const i32x4 yrs = skp_make_rsrc(a.y + blockIdx.z * a.y_split_stride, a.y_bytes);
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
     const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    // residual rows are requested two output channels ahead of their use (one exposed latency, bounded registers)
+    f32x4 rr[4][2][4];
+    float bvs[4];
+    auto load_res = [&](int r) {
         const int co = n0 + 4 * kq + r;
-        const float bv = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
             const bool ok = t_ok[tb] && co < a.Cout;
             const int vo = (o_base[tb] + co * HW) * 4;
-            f32x4 rr[4];
 #pragma unroll
-            for (int oy = 0; oy < 4; ++oy) rr[oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            for (int oy = 0; oy < 4; ++oy) rr[r][tb][oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 4 * kq + r;
+        bvs[r] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
+    }
+    load_res(0);
+    load_res(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 4 * kq + r;
+        const float bv = bvs[r];
+        if (r + 2 < 4) load_res(r + 2);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const bool ok = t_ok[tb] && co < a.Cout;
+            const int vo = (o_base[tb] + co * HW) * 4;
             float t[6][4];                           // T = M A : rows of the 6x6 tile -> 4 columns
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -266,10 +285,10 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
                 for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
                 w4_out1d(m, yv);
 #pragma unroll
-                for (int oy = 0; oy < 4; ++oy) rr[oy][ox] += yv[oy] + bv;
+                for (int oy = 0; oy < 4; ++oy) rr[r][tb][oy][ox] += yv[oy] + bv;
             }
 #pragma unroll
-            for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
