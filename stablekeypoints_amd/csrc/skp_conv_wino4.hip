@@ -69,16 +69,18 @@ struct Wino4Args {
     int tilesX, tilesPerImg, nTiles;
     unsigned x_bytes, u_bytes, y_bytes;
     int steps;              // 16-channel stages per workgroup
+    int ntb, ncg, tb_per_xcd;   // tile blocks, 64-channel groups, tile blocks per XCD band
     size_t y_split_stride;
 };
 
 constexpr int W4_STAGE_F4 = 36 * 4 * 32;          // f32x4 per stage: [36 positions][4 k-quads][32 tiles]
 constexpr int W4_RING = 12;                       // filter ring slots (divides 36); prefetch distance RING-1 positions
 
-// B^T applied to a 6-vector
-__device__ __forceinline__ void w4_in1d(const float (&d)[6], float (&t)[6]) {
-    const float a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
-    const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+// B^T applied to a 6-vector (T = float, or float2 for two columns at once on the packed-fp32 VALU ops)
+template <class T>
+__device__ __forceinline__ void w4_in1d(const T (&d)[6], T (&t)[6]) {
+    const T a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1];
+    const T c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
     t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
     t[1] = a + b;
     t[2] = a - b;
@@ -99,8 +101,23 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int tile0 = blockIdx.x * 32;
-    const int n0 = (blockIdx.y * 4 + wave) * 16;
+    // XCD-aware work order: workgroup ids are dealt round-robin to the 8 XCDs, so XCD k = id % 8 takes a contiguous band
+    // of tile blocks and walks it with the output-channel group fastest; the workgroups resident on one XCD then share
+    // their input tiles (all channel groups of a tile block, vertical halos of neighbouring blocks) in that XCD's L2.
+    // Layers with few tile blocks (L2-resident anyway) keep the plain order.
+    int tblock, cg;
+    if (a.tb_per_xcd > 0) {
+        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+        const int tb_local = seq / a.ncg;
+        cg = seq - tb_local * a.ncg;
+        tblock = xcd * a.tb_per_xcd + tb_local;
+        if (tblock >= a.ntb) return;                             // ragged band (whole workgroup)
+    } else {
+        cg = blockIdx.x / a.ntb;
+        tblock = blockIdx.x - cg * a.ntb;
+    }
+    const int tile0 = tblock * 32;
+    const int n0 = (cg * 4 + wave) * 16;
     const int HW = a.H * a.W;
     const int nsteps = a.steps;
     const int cin_begin = blockIdx.z * nsteps * 16;
@@ -126,29 +143,31 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     }
     const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
     const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
-    float d[2][6][6];                                // [channel][row][col]
+    // patch registers [channel][row][column pair]: pairs (c0,c5), (c1,c2), (c3,c4) -- the aligned 4-column load lands in
+    // two pairs, the two halo scalars share the third -- so the vertical pass runs on v_pk_* ops, two columns per op
+    f32x2 d[2][6][3];
     auto load_row = [&](int cin0, int e, int i) {    // one patch row: left scalar, 4 aligned columns, right scalar
         const int so = (cin0 + e) * HW * 4;
         const f32x4 mid = skp_buf_load_f32x4(xrs, roff[i], so, 0);
-        d[e][i][0] = skp_buf_load_f32(xrs, lok ? roff[i] - 4 : SKP_OOB, so, 0);
-        d[e][i][1] = mid[0]; d[e][i][2] = mid[1]; d[e][i][3] = mid[2]; d[e][i][4] = mid[3];
-        d[e][i][5] = skp_buf_load_f32(xrs, rok ? roff[i] + 16 : SKP_OOB, so, 0);
+        d[e][i][0][0] = skp_buf_load_f32(xrs, lok ? roff[i] - 4 : SKP_OOB, so, 0);
+        d[e][i][1] = f32x2{mid[0], mid[1]};
+        d[e][i][2] = f32x2{mid[2], mid[3]};
+        d[e][i][0][1] = skp_buf_load_f32(xrs, rok ? roff[i] + 16 : SKP_OOB, so, 0);
     };
-    auto col_pass = [&](int j) {                     // d[:, :, j] <- B^T d[:, :, j]   (vertical pass, both channels)
+    auto col_pass = [&](int e, int k) {              // d[e][:, pair k] <- B^T d[e][:, pair k]   (vertical pass)
+        f32x2 v[6], t[6];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float v[6], t[6];
+        for (int i = 0; i < 6; ++i) v[i] = d[e][i][k];
+        w4_in1d(v, t);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = d[e][i][j];
-            w4_in1d(v, t);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) d[e][i][j] = t[i];
-        }
+        for (int i = 0; i < 6; ++i) d[e][i][k] = t[i];
     };
     auto row_pass_store = [&](int buf, int i) {      // V[i][:] = (row i) B, both channels, written as float2 (channels 2cp, 2cp+1)
+        float r0[6] = {d[0][i][0][0], d[0][i][1][0], d[0][i][1][1], d[0][i][2][0], d[0][i][2][1], d[0][i][0][1]};
+        float r1[6] = {d[1][i][0][0], d[1][i][1][0], d[1][i][1][1], d[1][i][2][0], d[1][i][2][1], d[1][i][0][1]};
         float t0[6], t1[6];
-        w4_in1d(d[0][i], t0);
-        w4_in1d(d[1][i], t1);
+        w4_in1d(r0, t0);
+        w4_in1d(r1, t1);
         float* dst = (float*)(vst + buf * W4_STAGE_F4) + (((i * 6) * 4 + (cp >> 1)) * 32 + tl) * 4 + 2 * (cp & 1);
 #pragma unroll
         for (int j = 0; j < 6; ++j) *(f32x2*)(dst + j * (4 * 32 * 4)) = f32x2{t0[j], t1[j]};
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) { load_row(cin_begin, 0, i); load_row(cin_begin, 1, i); }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) col_pass(j);
+    for (int k = 0; k < 3; ++k) { col_pass(0, k); col_pass(1, k); }
 #pragma unroll
     for (int i = 0; i < 6; ++i) row_pass_store(0, i);
     f32x4 ua[W4_RING];
@@ -195,9 +214,11 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
         constexpr int MODE = decltype(mode_c)::value;
         const f32x4* vb = vst + (s & 1) * W4_STAGE_F4 + kq * 32 + i16;
         const int ub = ((cin_begin >> 4) + s) * u_c16;
-        f32x4 va[2][2];
+        f32x4 va[3][2];                              // LDS operands two positions ahead (LDS latency > one position's MFMAs)
         va[0][0] = vb[0];
         va[0][1] = vb[16];
+        va[1][0] = vb[128];
+        va[1][1] = vb[128 + 16];
 #pragma unroll
         for (int p = 0; p < 36; ++p) {
             {   // filter operand for position p + RING-1 (wrapping into the next stage)
@@ -213,20 +234,20 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
                     load_row(cin_begin + (s + 1) * 16, 0, p);
                     load_row(cin_begin + (s + 1) * 16, 1, p);
                 } else if (p >= 24 && p < 30) {
-                    col_pass(p - 24);
+                    col_pass((p - 24) & 1, (p - 24) >> 1);
                 } else if (p >= 30) {
                     row_pass_store((s + 1) & 1, p - 30);
                 }
             }
-            if (p + 1 < 36) {
-                va[(p + 1) & 1][0] = vb[(p + 1) * 128];
-                va[(p + 1) & 1][1] = vb[(p + 1) * 128 + 16];
+            if (p + 2 < 36) {
+                va[(p + 2) % 3][0] = vb[(p + 2) * 128];
+                va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int tb = 0; tb < 2; ++tb)
-                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4_RING][m], va[p & 1][tb][m], acc[p][tb], 0, 0, 0);
+                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4_RING][m], va[p % 3][tb][m], acc[p][tb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -375,7 +396,10 @@ extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((a.nTiles + 31) / 32, (Cout + 63) / 64, S);
+    a.ntb = (a.nTiles + 31) / 32;
+    a.ncg = (Cout + 63) / 64;
+    a.tb_per_xcd = a.ntb >= 32 ? (a.ntb + 7) / 8 : 0;
+    dim3 grid(a.tb_per_xcd ? 8 * a.tb_per_xcd * a.ncg : a.ntb * a.ncg, 1, S);
     hipLaunchKernelGGL(skp_wino4_conv_kernel, grid, dim3(256), lds, st, a);
     int rc = skp_launch_status();
     if (rc || S == 1) return rc;

@@ -11,15 +11,42 @@ import torch  # noqa: E402
 from stablekeypoints_amd import _native as N, ops  # noqa: E402
 
 
+def _timed(name, fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:28s} {e0.elapsed_time(e1) / iters * 1e3:9.1f} us")
+
+
+def conv_part(a, dev, g):
+    """Winograd conv3x3 at the heaviest VAE launch shapes of the step and one UNet shape."""
+    B = a.rows
+    for (ci, co, Hs) in ((128, 128, 512), (512, 512, 128), (1280, 1280, 16)):
+        x = torch.randn(B, ci, Hs, Hs, generator=g).to(dev)
+        w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(dev)
+        U4 = ops._wino4_filters(w, False)
+        _timed(f"conv3x3 F(4,3) {ci}->{co} {Hs}^2", lambda: ops._conv3x3_f4_raw(x, U4, None, co), a.iters)
+        U2 = ops._wino_filters(w, False)
+        _timed(f"conv3x3 F(2,3) {ci}->{co} {Hs}^2", lambda: ops._conv3x3_raw(x, U2, None, co), a.iters)
+        del x, w, U4, U2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=8)
     ap.add_argument("--tokens", type=int, default=77)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--what", default="all", choices=["all", "conv", "noconv"])
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
+    if a.what == "conv":
+        return conv_part(a, dev, g)
     B, T, R, H = a.rows, a.tokens, a.res, 8
     dims = [(16, 1280)] * 3 + [(32, 640)]
     qs = [torch.randn(B, s * s, C, generator=g).to(dev) for s, C in dims]
@@ -64,6 +91,8 @@ def main():
     for (n, C) in ((4096, 320), (1024, 640), (256, 1280)):
         q = torch.randn(B, n, C, generator=g).to(dev); k = torch.randn(1, T, C, generator=g).to(dev); v = torch.randn(1, T, C, generator=g).to(dev)
         timed(f"cross_attn_fwd N={n} C={C}", lambda: ops.cross_attention(q, k, v, H, (C // H) ** -0.5))
+    if a.what != "noconv":
+        conv_part(a, dev, g)
 
 
 if __name__ == "__main__":
