@@ -134,6 +134,30 @@ def self_attn_roofline(ops, B, iters, device):
     return out, flops_fwd, 2.5 * flops_fwd
 
 
+def conv_roofline(ops, B, image_size, iters, device):
+    """The Winograd F(4x4,3x3) conv kernel at the heaviest launch shape of the step: the VAE encoder's first-level
+    ResnetBlock2D convs (128 -> 128 channels at image resolution, B rows).  Executed MFMA FLOPs = direct-form FLOPs / 4
+    (36 multiplies per 4x4 output tile and channel pair instead of 144); algorithmic bytes = input + output + filter."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    ci = co = 128
+    x = torch.randn(B, ci, image_size, image_size, generator=g).to(device)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
+    U = ops._wino4_filters(w, False)
+    fn = lambda: ops._conv3x3_f4_raw(x, U, None, co)
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    direct = 2.0 * 9 * ci * co * B * image_size * image_size
+    nbytes = 4 * (B * ci * image_size ** 2 + B * co * image_size ** 2 + 36 * ci * co)
+    grid_threads = 8 * ((((B * (image_size // 4) ** 2 + 31) // 32) + 7) // 8) * ((co + 63) // 64) * 256
+    return t, direct, nbytes, grid_threads
+
+
 def cpu_baseline(ldm_cpu, args):
     """Oracle reference-order CPU step (oracle/cpu_path.py) on a bounded sample: ONE image (2 UNet+VAE
     forwards with materialised attention + backward + Adam) at --cpu-image-size, after one untimed warm-up
@@ -157,16 +181,15 @@ def measured_traffic(kernel_substr):
     FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at the same launch shape; FETCH_SIZE doubled per
     MI355X_MICROARCH.md 'HBM').  None when no profile is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels_*.json")))
-    if not files:
-        return None
-    try:
-        k = json.load(open(files[-1]))["kernels"]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True)       # newest round / version first by name
+    for path in files:
+        try:
+            k = json.load(open(path))["kernels"]
+        except Exception:
+            continue
         for name, c in k.items():
             if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
-    except Exception:
-        return None
     return None
 
 
@@ -254,6 +277,7 @@ def main():
         B = 2 * per_rank                                          # rows per fused-map launch (both views)
         kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev)
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(3, a.kernel_iters // 6), dev)
+        cv_t, cv_direct, cv_bytes, cv_grid = conv_roofline(ops, B, a.image_size, max(3, a.kernel_iters // 6), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
         line = {
@@ -266,7 +290,17 @@ def main():
                                    f"T={a.tokens} tokens, R={a.res}, top_k=10 of 25, fp32 end to end",
                        "global_batch": global_batch, "images_per_rank": per_rank, "tokens": a.tokens,
                        "feature_upsample_res": a.res, "parallelism": f"dp{world}"},
-            "roofline": {"kernel": "skp_attn_map_fwd_kernel<80,0> (fused up-res softmax map, forward)",
+            # dominant kernel of the step by time (37 % of it): the Winograd conv of the frozen blocks, priced on the
+            # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
+            "roofline": {"kernel": f"skp_wino4_conv_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {a.image_size}^2, "
+                                   f"{B} rows: heaviest launch shape of the step)",
+                         "bound": "mfma", "achieved": cv_direct / 4 / cv_t / 1e12, "peak": F32_MATRIX_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": cv_direct / 4 / cv_t / 1e12 / F32_MATRIX_PEAK_TF,
+                         "traffic": measured_traffic(f"skp_wino4_conv_kernel@grid{cv_grid}"),
+                         "launch_us": cv_t * 1e6, "algorithmic_flops": cv_direct / 4, "algorithmic_bytes": cv_bytes,
+                         "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
+                         "rows_per_launch": B, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
+            "roofline_attn_map": {"kernel": "skp_attn_map_fwd_kernel<80,0> (fused up-res softmax map, forward)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("skp_attn_map_fwd_kernel"),
                          "launch_us": kt["fwd"] * 1e6, "algorithmic_bytes": fwd_bytes, "rows_per_launch": B,
@@ -282,6 +316,8 @@ def main():
             "cpu_baseline": cpu_stats,
             "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1,
         }
+        if line["roofline"]["traffic"]:
+            line["roofline"]["hbm_gbs_at_traffic"] = line["roofline"]["traffic"] / cv_t / 1e9
         print(json.dumps(line), flush=True)
     D.barrier()
     if world > 1:

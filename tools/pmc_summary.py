@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\\(anonymous namespace\\)::", "", name)
+    name = name.replace("(anonymous namespace)::", "")
     return name.split("(")[0].strip()
 
 
@@ -23,6 +23,8 @@ def main():
                 k = short(row["Kernel_Name"])
                 if "skp_" not in k:
                     continue
+                if "conv_kernel" in k:                      # one kernel, several launch shapes: key by grid size too
+                    k += "@grid" + row["Grid_Size"]
                 key = (k, row["Counter_Name"])
                 d = per.setdefault(key, {})
                 disp = row["Dispatch_Id"]
