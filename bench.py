@@ -233,6 +233,8 @@ def main():
         from stablekeypoints_amd.ldm.fused import fuse_norms
         fuse_norms(ldm.unet)
         fuse_norms(ldm.vae)
+    from stablekeypoints_amd import tuning
+    gemm_tuned = tuning.enable()
     t_build = time.time() - t_build
 
     per_rank = a.images_per_rank
@@ -314,7 +316,7 @@ def main():
                                    "bwd_us": sa["bwd"] * 1e6, "bwd_achieved": sa_b / sa["bwd"] / 1e12,
                                    "rows_per_launch": B, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
             "cpu_baseline": cpu_stats,
-            "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1,
+            "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
         }
         if line["roofline"]["traffic"]:
             line["roofline"]["hbm_gbs_at_traffic"] = line["roofline"]["traffic"] / cv_t / 1e9

@@ -31,6 +31,8 @@ def load_ldm(device, type="CompVis/stable-diffusion-v1-4", feature_upsample_res=
         from .ldm.fused import fuse_norms
         fuse_norms(ldm.unet)
         fuse_norms(ldm.vae)
+        from . import tuning
+        tuning.enable()                                 # measured GEMM algorithm choices for the frozen Linear layers
     for module in (ldm.vae, ldm.text_encoder, ldm.unet):
         for p in module.parameters():
             p.requires_grad = False

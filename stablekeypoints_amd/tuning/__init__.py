@@ -1,0 +1,32 @@
+"""GEMM algorithm selection for the frozen nn.Linear layers (hipBLASLt / rocBLAS through PyTorch's TunableOp).
+
+`tunableop_gfx950.csv` holds the per-shape winners measured once on an MI355X for the GEMM shapes of the SD-1.5
+512^2 step (`PYTORCH_TUNABLEOP_TUNING=1 python bench.py`, 2.5 minutes).  `enable()` loads it read-only: no
+tuning happens at run time, shapes that are not in the file use the library default, and PyTorch ignores the
+file when its validators (ROCm / hipBLASLt / rocBLAS versions, GPU architecture) do not match.  Results stay
+fp32; measured -2.4 % step time (103.1 -> 100.7 ms).  `SKP_TUNABLEOP=0` turns it off."""
+import os
+
+_done = False
+
+
+def enable() -> bool:
+    global _done
+    if _done or os.environ.get("SKP_TUNABLEOP", "1") == "0":
+        return _done
+    try:
+        import torch
+        from torch.cuda import tunable
+        if not torch.cuda.is_available():
+            return False
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+        tunable.enable(True)
+        tunable.tuning_enable(os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") == "1")
+        import tempfile
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), "skp_tunableop_unused.csv"))   # never write into the repo
+        if os.path.exists(path):
+            tunable.read_file(path)
+        _done = True
+    except Exception:                                   # older torch / no TunableOp: library defaults
+        _done = False
+    return _done
