@@ -154,7 +154,7 @@ def conv_roofline(ops, B, image_size, iters, device):
     t = e0.elapsed_time(e1) / iters * 1e-3
     direct = 2.0 * 9 * ci * co * B * image_size * image_size
     nbytes = 4 * (B * ci * image_size ** 2 + B * co * image_size ** 2 + 36 * ci * co)
-    grid_threads = 8 * ((((B * (image_size // 4) ** 2 + 31) // 32) + 7) // 8) * ((co + 63) // 64) * 256
+    grid_threads = 8 * ((((B * (image_size // 4) ** 2 + 15) // 16) + 7) // 8) * (co // 128) * 256   # 128-channel form
     return t, direct, nbytes, grid_threads
 
 
@@ -294,11 +294,11 @@ def main():
                        "feature_upsample_res": a.res, "parallelism": f"dp{world}"},
             # dominant kernel of the step by time (37 % of it): the Winograd conv of the frozen blocks, priced on the
             # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
-            "roofline": {"kernel": f"skp_wino4_conv_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {a.image_size}^2, "
+            "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {a.image_size}^2, "
                                    f"{B} rows: heaviest launch shape of the step)",
                          "bound": "mfma", "achieved": cv_direct / 4 / cv_t / 1e12, "peak": F32_MATRIX_PEAK_TF,
                          "unit": "TFLOP/s", "frac": cv_direct / 4 / cv_t / 1e12 / F32_MATRIX_PEAK_TF,
-                         "traffic": measured_traffic(f"skp_wino4_conv_kernel@grid{cv_grid}"),
+                         "traffic": measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}"),
                          "launch_us": cv_t * 1e6, "algorithmic_flops": cv_direct / 4, "algorithmic_bytes": cv_bytes,
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
                          "rows_per_launch": B, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},

@@ -23,7 +23,7 @@ def main():
                 k = short(row["Kernel_Name"])
                 if "skp_" not in k:
                     continue
-                if "conv_kernel" in k:                      # one kernel, several launch shapes: key by grid size too
+                if "_conv_" in k:                      # one kernel, several launch shapes: key by grid size too
                     k += "@grid" + row["Grid_Size"]
                 key = (k, row["Counter_Name"])
                 d = per.setdefault(key, {})
