@@ -140,6 +140,7 @@ def conv_roofline(ops, B, image_size, iters, device):
     (36 multiplies per 4x4 output tile and channel pair instead of 144); algorithmic bytes = input + output + filter."""
     g = torch.Generator(device="cpu").manual_seed(2)
     ci = co = 128
+    B = min(B, max(1, (2 ** 31 - 1) // (ci * image_size * image_size * 4)))   # one launch (the op chunks larger batches)
     x = torch.randn(B, ci, image_size, image_size, generator=g).to(device)
     w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
     U = ops._wino4_filters(w, False)
@@ -155,7 +156,7 @@ def conv_roofline(ops, B, image_size, iters, device):
     direct = 2.0 * 9 * ci * co * B * image_size * image_size
     nbytes = 4 * (B * ci * image_size ** 2 + B * co * image_size ** 2 + 36 * ci * co)
     grid_threads = 8 * ((((B * (image_size // 4) ** 2 + 15) // 16) + 7) // 8) * (co // 128) * 256   # 128-channel form
-    return t, direct, nbytes, grid_threads
+    return t, direct, nbytes, grid_threads, B
 
 
 def cpu_baseline(ldm_cpu, args):
@@ -279,7 +280,7 @@ def main():
         B = 2 * per_rank                                          # rows per fused-map launch (both views)
         kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev)
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(3, a.kernel_iters // 6), dev)
-        cv_t, cv_direct, cv_bytes, cv_grid = conv_roofline(ops, B, a.image_size, max(3, a.kernel_iters // 6), dev)
+        cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, a.image_size, max(3, a.kernel_iters // 6), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
         line = {
@@ -295,13 +296,13 @@ def main():
             # dominant kernel of the step by time (37 % of it): the Winograd conv of the frozen blocks, priced on the
             # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
             "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {a.image_size}^2, "
-                                   f"{B} rows: heaviest launch shape of the step)",
+                                   f"{cv_rows} rows: heaviest launch shape of the step)",
                          "bound": "mfma", "achieved": cv_direct / 4 / cv_t / 1e12, "peak": F32_MATRIX_PEAK_TF,
                          "unit": "TFLOP/s", "frac": cv_direct / 4 / cv_t / 1e12 / F32_MATRIX_PEAK_TF,
                          "traffic": measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}"),
                          "launch_us": cv_t * 1e6, "algorithmic_flops": cv_direct / 4, "algorithmic_bytes": cv_bytes,
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
-                         "rows_per_launch": B, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
+                         "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
             "roofline_attn_map": {"kernel": "skp_attn_map_fwd_kernel<80,0> (fused up-res softmax map, forward)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("skp_attn_map_fwd_kernel"),

@@ -460,8 +460,10 @@ def conv3x3_supported(x_shape, w_shape, need_grad=True):
     co, ci = int(w_shape[0]), int(w_shape[1])
     if co % 32 or ci % 32:
         return False
-    b, _, h, w = (int(v) for v in x_shape)
-    return max(b * ci * h * w, b * co * h * w, 16 * ci * co) * 4 < 2 ** 31
+    _, _, h, w = (int(v) for v in x_shape)
+    # the kernels address each tensor with 32-bit byte offsets (< 2 GiB per launch); larger batches are launched in
+    # batch chunks (_conv3x3_run), so the limit applies to one image
+    return max(ci * h * w, co * h * w, 16 * ci * co) * 4 < 2 ** 31
 
 
 def _wino_filters(weight, backward):
@@ -481,9 +483,9 @@ def _wino_filters(weight, backward):
     return U
 
 
-def _conv3x3_raw(x, U, bias, cout, variant=0, split=True, residual=None):
+def _conv3x3_raw(x, U, bias, cout, variant=0, split=True, residual=None, out=None):
     B, ci, H, W = x.shape
-    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     nbytes = N.lib().skp_conv3x3_workspace(B, ci, cout, H, W, int(variant)) if split else 0
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     N.check(N.lib().skp_conv3x3_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -510,9 +512,9 @@ def _wino4_filters(weight, backward):
     return U
 
 
-def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None):
+def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None, out=None):
     B, ci, H, W = x.shape
-    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     nbytes = N.lib().skp_conv3x3_f4_workspace(B, ci, cout, H, W) if split else 0
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     N.check(N.lib().skp_conv3x3_f4_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -544,9 +546,19 @@ def conv3x3_wanted(x_shape, w_shape):
 
 def _conv3x3_run(x, weight, backward, bias, residual, cout):
     w_shape = (weight.shape[1], weight.shape[0], 3, 3) if backward else weight.shape
-    if conv3x3_f4_ok(x.shape, w_shape):
-        return _conv3x3_f4_raw(x, _wino4_filters(weight, backward), bias, cout, residual=residual)
-    return _conv3x3_raw(x, _wino_filters(weight, backward), bias, cout, residual=residual)
+    f4 = conv3x3_f4_ok(x.shape, w_shape)
+    U = _wino4_filters(weight, backward) if f4 else _wino_filters(weight, backward)
+    run = _conv3x3_f4_raw if f4 else _conv3x3_raw
+    B, ci, H, W = x.shape
+    per_image = max(ci, cout) * H * W * 4
+    chunk = max(1, (2 ** 31 - 1) // per_image)           # rows per launch under the kernels' 2 GiB addressing limit
+    if B <= chunk:
+        return run(x, U, bias, cout, residual=residual)
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    for b0 in range(0, B, chunk):
+        b1 = min(B, b0 + chunk)
+        run(x[b0:b1], U, bias, cout, residual=None if residual is None else residual[b0:b1], out=y[b0:b1])
+    return y
 
 
 class Conv3x3Fn(torch.autograd.Function):

@@ -447,3 +447,17 @@ def test_geglu_and_layout_kernels(ops):
         gy = torch.randn(B, C, H, W, generator=g).cuda()
         (back * gy).sum().backward()
         assert torch.equal(x.grad, gy) and torch.equal(r.grad, gy)
+
+
+def test_winograd_conv3x3_batch_chunking_over_2gib(ops):
+    """Tensors above the kernels' 2 GiB per-launch addressing limit are launched in batch chunks: same result as the
+    per-image launches."""
+    g = torch.Generator().manual_seed(29)
+    B, C, H = 5, 128, 1024                                  # 5 x 128 x 1024^2 x 4 B = 2.5 GiB
+    x = torch.randn(B, C, H, H, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).cuda()
+    b = torch.randn(C, generator=g).cuda()
+    y = ops.conv3x3(x, w, b)
+    for i in (0, 3, 4):
+        yi = ops.conv3x3(x[i:i + 1].contiguous(), w, b)
+        assert torch.equal(y[i:i + 1], yi)
