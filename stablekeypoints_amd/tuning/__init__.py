@@ -23,7 +23,7 @@ def enable() -> bool:
         tunable.enable(True)
         tunable.tuning_enable(os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") == "1")
         import tempfile
-        tunable.set_filename(os.path.join(tempfile.gettempdir(), "skp_tunableop_unused.csv"))   # never write into the repo
+        tunable.set_filename(os.path.join(tempfile.gettempdir(), f"skp_tunableop_unused_{os.getpid()}.csv"))   # exit-time dump: never into the repo, one file per process
         if os.path.exists(path):
             tunable.read_file(path)
         _done = True
