@@ -69,9 +69,34 @@ struct Wino4Args {
     int tilesX, tilesPerImg, nTiles;
     unsigned x_bytes, u_bytes, y_bytes;
     int steps;              // 16-channel stages per workgroup
-    int ntb, ncg, tb_per_xcd;   // tile blocks, 64-channel groups, tile blocks per XCD band
+    int ntb, ncg, tb_per_xcd;   // tile blocks, channel groups, tile blocks per XCD band (0: unit-grouped order)
+    int splits;                 // K splits
     size_t y_split_stride;
 };
+
+// Workgroup id -> (tile block, channel group, K split).  Ids are dealt round-robin to the 8 XCDs (each with its own
+// L2), so the order decides what the co-resident workgroups of an XCD share:
+//  * many tile blocks (tb_per_xcd > 0): XCD k = id % 8 takes a contiguous band of tile blocks and walks it with the
+//    channel group fastest -> input tiles (all channel groups of a block, vertical halos of neighbours) are shared;
+//  * few tile blocks (small-spatial UNet layers, operand-traffic bound): all tile blocks of one (split, channel group)
+//    unit go to the same XCD, unit u -> XCD u % 8, so the unit's filter slice is fetched into that L2 once.
+__device__ __forceinline__ bool w4_work(const Wino4Args& a, int& tblock, int& cg, int& z) {
+    if (a.tb_per_xcd > 0) {
+        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+        const int tb_local = seq / a.ncg;
+        cg = seq - tb_local * a.ncg;
+        tblock = xcd * a.tb_per_xcd + tb_local;
+        z = blockIdx.z;
+        return tblock < a.ntb;                                   // ragged band (whole workgroup)
+    }
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int ul = q / a.ntb;
+    tblock = q - ul * a.ntb;
+    const int u = ul * 8 + xcd;
+    z = u / a.ncg;
+    cg = u - z * a.ncg;
+    return u < a.ncg * a.splits;
+}
 
 constexpr int W4_STAGE_F4 = 36 * 4 * 32;          // f32x4 per stage: [36 positions][4 k-quads][32 tiles]
 constexpr int W4_RING = 12;                       // filter ring slots (divides 36); prefetch distance RING-1 positions
@@ -101,26 +126,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    // XCD-aware work order: workgroup ids are dealt round-robin to the 8 XCDs, so XCD k = id % 8 takes a contiguous band
-    // of tile blocks and walks it with the output-channel group fastest; the workgroups resident on one XCD then share
-    // their input tiles (all channel groups of a tile block, vertical halos of neighbouring blocks) in that XCD's L2.
-    // Layers with few tile blocks (L2-resident anyway) keep the plain order.
-    int tblock, cg;
-    if (a.tb_per_xcd > 0) {
-        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-        const int tb_local = seq / a.ncg;
-        cg = seq - tb_local * a.ncg;
-        tblock = xcd * a.tb_per_xcd + tb_local;
-        if (tblock >= a.ntb) return;                             // ragged band (whole workgroup)
-    } else {
-        cg = blockIdx.x / a.ntb;
-        tblock = blockIdx.x - cg * a.ntb;
-    }
+    int tblock, cg, zsplit;
+    if (!w4_work(a, tblock, cg, zsplit)) return;
     const int tile0 = tblock * 32;
     const int n0 = (cg * 4 + wave) * 16;
     const int HW = a.H * a.W;
     const int nsteps = a.steps;
-    const int cin_begin = blockIdx.z * nsteps * 16;
+    const int cin_begin = zsplit * nsteps * 16;
 
     // ---- transform role: the 6x6 patches of 2 consecutive channels of one tile ----
     const int tl = tid & 31, cp = tid >> 5;
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     run_stage(nsteps - 1, std::integral_constant<int, 1>{});
 
     // ---- output transform (in-lane) + store.  Branch-free: invalid tiles/channels store out of range (dropped). ----
-    const i32x4 yrs = skp_make_rsrc(a.y + blockIdx.z * a.y_split_stride, a.y_bytes);
+    const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
     const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
     // residual rows are requested two output channels ahead of their use (one exposed latency, bounded registers)
@@ -325,22 +337,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     extern __shared__ f32x4 vst[];                   // [2][36][4][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    int tblock, cg;
-    if (a.tb_per_xcd > 0) {                          // XCD-aware work order, see skp_wino4_conv_kernel
-        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-        const int tb_local = seq / a.ncg;
-        cg = seq - tb_local * a.ncg;
-        tblock = xcd * a.tb_per_xcd + tb_local;
-        if (tblock >= a.ntb) return;
-    } else {
-        cg = blockIdx.x / a.ntb;
-        tblock = blockIdx.x - cg * a.ntb;
-    }
+    int tblock, cg, zsplit;
+    if (!w4_work(a, tblock, cg, zsplit)) return;
     const int tile0 = tblock * 16;
     const int n0 = (cg * 4 + wave) * 32;             // this wave's 32 output channels (two 16-row MFMA blocks)
     const int HW = a.H * a.W;
     const int nsteps = a.steps;
-    const int cin_begin = blockIdx.z * nsteps * 16;
+    const int cin_begin = zsplit * nsteps * 16;
 
     // ---- transform role: the 6x6 patch of one channel of one tile ----
     const int tl = tid & 15, tc = tid >> 4;          // tile in the block, channel in the stage
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     }
     run_stage(nsteps - 1, std::integral_constant<int, 1>{});
 
-    const i32x4 yrs = skp_make_rsrc(a.y + blockIdx.z * a.y_split_stride, a.y_bytes);
+    const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
     const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
     f32x4 rr[8][4];                                  // [channel block * 4 + r][output row]
@@ -584,6 +587,7 @@ extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias
     a.nTiles = B * a.tilesPerImg;
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
     a.steps = Cin / 16 / S;
+    a.splits = S;
     const size_t out_elems = (size_t)B * Cout * H * W;
     a.y_split_stride = out_elems;
     a.y = S > 1 ? (float*)workspace : (float*)y;
@@ -606,13 +610,13 @@ extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias
         a.ntb = (a.nTiles + 15) / 16;
         a.ncg = Cout / 128;
         a.tb_per_xcd = a.ntb >= 64 ? (a.ntb + 7) / 8 : 0;
-        dim3 grid(a.tb_per_xcd ? 8 * a.tb_per_xcd * a.ncg : a.ntb * a.ncg, 1, S);
+        dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
         hipLaunchKernelGGL(skp_wino4_conv_c128_kernel, grid, dim3(256), lds_c, st, a);
     } else {                                        // 64 channels x 32 tiles per workgroup
         a.ntb = (a.nTiles + 31) / 32;
         a.ncg = (Cout + 63) / 64;
         a.tb_per_xcd = a.ntb >= 32 ? (a.ntb + 7) / 8 : 0;
-        dim3 grid(a.tb_per_xcd ? 8 * a.tb_per_xcd * a.ncg : a.ntb * a.ncg, 1, S);
+        dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
         hipLaunchKernelGGL(skp_wino4_conv_kernel, grid, dim3(256), lds, st, a);
     }
     int rc = skp_launch_status();
