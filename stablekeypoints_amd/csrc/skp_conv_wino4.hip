@@ -4,14 +4,20 @@
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          6x6 transform domain, interpolation points 0, +-1, +-2, inf
 //
-// Work split (v_mfma_f32_16x16x4_f32): a wave owns 16 output channels x 32 tiles (two 16-tile column blocks) x all
-// 36 positions = 72 accumulator tiles of 4 registers (288 of the 512 registers of its SIMD), so the output transform
-// stays in-lane.  A workgroup = 4 waves = 64 output channels on the same 32 tiles; it transforms the 32 x 16-channel
-// input patches of a stage into LDS once (double buffered, 2 x 72 KB) in MFMA operand order.  The transformed filter
-// is streamed from L2 through a 12-position register ring (VMEM returns in order: everything queued behind a patch
-// load inherits its HBM latency, so the ring has to cover it).  The patch loads of the next stage are issued in the
-// first positions of the MFMA loop and their 6x6 transform + LDS writes are spread over the last positions, so the
-// matrix pipe does not wait for the VALU work.  fp32 throughout; relative error ~3e-6 of the output maximum.
+// Work split (v_mfma_f32_16x16x4_f32), two workgroup forms with the same 288 accumulator registers per wave (of the
+// 512 registers of its SIMD: one wave per SIMD), so that the 6x6 -> 4x4 output transform stays in-lane:
+//   * skp_wino4_conv_kernel:      wave = 16 output channels x 32 tiles x 36 positions, workgroup = 64 channels x 32 tiles
+//   * skp_wino4_conv_c128_kernel: wave = 32 output channels x 16 tiles x 36 positions, workgroup = 128 channels x 16 tiles
+//     (Cout % 128 == 0 and >= 256 tiles): half the input-transform work per MFMA, two filter loads per position.
+// The workgroup transforms the input patches of a 16-channel stage into LDS once (double buffered, 2 x 72 / 36 KB) in
+// MFMA operand order.  The transformed filter is streamed from L2 through a register ring (12 / 6 positions deep; VMEM
+// returns in order: everything queued behind a patch load inherits its latency, so the ring has to cover it).  The
+// patch loads of the next stage are issued in the first positions of the MFMA loop and their 6x6 transform + LDS writes
+// are spread over the last positions.  With one wave per SIMD every non-MFMA instruction is exposed, so the loop is
+// kept to: one (two) filter load(s), two (one) LDS operand reads and 8 MFMAs per position, plus those side jobs.
+// Zero padding, ragged tile blocks, idle channel rows, bias and residual all go through raw buffer loads / stores whose
+// out-of-range offsets return 0 / are dropped: no divergent branch anywhere near the accumulators (a branch around
+// them costs hundreds of spilled registers).  fp32 throughout; relative error ~1e-5 of the output maximum.
 #include <type_traits>
 #include "skp_common.h"
 
