@@ -182,3 +182,24 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert lib.skp_select_tokens(p, p, 77, 128, 25, 1, p, p, null) == -2                  # top_k < 2
     assert lib.skp_token_stats_f32(p, 77, 128, 9, 2.0, 1e-5, p, null, null) == -2          # too many subjects
     assert lib.skp_losses_fwd_f32(p, p, p, 10, 77, 128, p, 1, 2.0, None, p, p, p, p, null) == -1
+
+
+def test_tuning_module_is_inert_without_a_gpu():
+    """The GEMM algorithm file is only read on a GPU box; on CPU `enable()` is a no-op and never raises."""
+    from stablekeypoints_amd import tuning
+    import os
+    assert os.path.exists(os.path.join(os.path.dirname(tuning.__file__), "tunableop_gfx950.csv"))
+    if not torch.cuda.is_available():
+        assert tuning.enable() is False
+
+
+def test_conv3x3_shape_rules():
+    """Which 3x3 convolutions go to the Winograd kernels (pure host logic, no launches)."""
+    from stablekeypoints_amd import ops
+    assert ops.conv3x3_supported((8, 128, 512, 512), (128, 128, 3, 3))
+    assert not ops.conv3x3_supported((8, 4, 64, 64), (320, 4, 3, 3))            # conv_in: 4 channels -> library
+    assert not ops.conv3x3_supported((8, 128, 64, 64), (128, 128, 1, 1))
+    assert ops.conv3x3_f4_ok((8, 320, 64, 64), (320, 320, 3, 3)) == (ops.CONV3X3_MODE == "f4")
+    assert not ops.conv3x3_f4_ok((8, 320, 66, 64), (320, 320, 3, 3))            # H % 4 != 0 -> F(2x2,3x3)
+    assert ops.conv3x3_wanted((8, 320, 66, 64), (320, 320, 3, 3)) == (ops.CONV3X3_MODE != "lib")
+    assert not ops.conv3x3_wanted((1, 32, 4, 4), (32, 32, 3, 3))               # too few tiles -> library
