@@ -187,12 +187,15 @@ int skp_tokens_to_nchw_f32(const float* t, const float* residual, float* y, int 
  *   argmax[j*T+t] (i32) = flat index (row*R+col) of the j-th masked maximum, j<num_subjects
  *                         (first index wins ties; radius 0.05*R masking between maxima)
  *   kl[t] = KL( normalised gaussian(sigma) at those maxima  ||  softmax_{R*R}(M[t]+eps) )
- * kl may be NULL (argmax only). */
+ *   entropy[t] = entropy of Categorical(probs = softmax_{R*R}(M[t]))   (ptp_utils.py:165-187 entropy_sort: probs
+ *                renormalised, log of the probs clamped to [FLT_EPSILON, 1-FLT_EPSILON] as torch.distributions does)
+ * kl and entropy may each be NULL (not computed). */
 int skp_token_stats_f32(const float* M, int T, int R, int num_subjects, float sigma, float eps,
-                        int32_t* argmax, float* kl, void* stream);
+                        int32_t* argmax, float* kl, float* entropy, void* stream);
 
 /* Token selection (ptp_utils.py:110-112 + 115-159), entirely on device:
- *   cand = first n_cand tokens of argsort(kl, ascending)
+ *   cand = first n_cand tokens of argsort(kl, ascending)  (`kl` is any per-token score: KL, entropy, or a fixed
+ *          order; ties by index; NaN scores rank after every number, as torch.argsort does)
  *   sel  = furthest_point_sampling over cand using the arg-max locations of the
  *          TRANSFORMED map (argmax_t, i32 flat indices, grid side R)
  * cand: i64[n_cand], sel: i64[top_k].  Limits: T <= 1024, n_cand <= 64, 2 <= top_k <= n_cand. */
@@ -207,7 +210,8 @@ int skp_select_tokens(const float* kl, const int32_t* argmax_t, int T, int R, in
  * warp is affine_grid + bilinear grid_sample, zeros padding, align_corners=False.
  * partial: [2,K,nchunk] sums of squares, nchunk = ceil(R*R/1024) (caller sums, divides by K*R*R);
  * g_sharp, g_eq_a: [K,R,R] written = d sharp / d M[sel], d equiv / d M[sel];
- * g_eq_b: [K,R,R] must be ZERO-FILLED, accumulates d equiv / d Mt[sel] (fp32 atomics). */
+ * g_eq_b: [K,R,R] written = d equiv / d Mt[sel], computed as a gather over the bilinear footprints (a second
+ *         kernel on the same stream; no atomics, bit-reproducible). */
 int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
                        const int32_t* argmax, int num_subjects, float sigma,
                        const float* theta_inv /*[host] 6*/, float* partial, float* g_sharp,

@@ -56,14 +56,16 @@ def maps_for(ldm, image, context, store, noise, layers=(0, 1, 2, 3), noise_level
 
 
 def image_step(ldm, image, context, store, theta, noise, noise_t, *, layers=(0, 1, 2, 3), sigma=2.0,
-               furthest_point_num_samples=25, top_k=10, num_subjects=1, w_sharp=100.0, w_equiv=1000.0):
+               furthest_point_num_samples=25, top_k=10, num_subjects=1, w_sharp=100.0, w_equiv=1000.0,
+               top_k_strategy="gaussian"):
     """optimize.py:347-414 for one image (G=1): returns (loss, sharp, equiv, sel, map, map_t)."""
     am = maps_for(ldm, image, context, store, noise, layers)
     warped = R.affine_warp(image, theta)
     am_t = maps_for(ldm, warped, context, store, noise_t, layers)
     loss, sharp, equiv, sel = R.image_loss(am, am_t, theta, 0, furthest_point_num_samples=furthest_point_num_samples,
                                            top_k=top_k, sigma=sigma, num_subjects=num_subjects,
-                                           sharpening_loss_weight=w_sharp, equivariance_attn_loss_weight=w_equiv)
+                                           sharpening_loss_weight=w_sharp, equivariance_attn_loss_weight=w_equiv,
+                                           top_k_strategy=top_k_strategy)
     return loss, sharp, equiv, sel, am, am_t
 
 

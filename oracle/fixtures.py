@@ -61,6 +61,12 @@ E2E_CASE = dict(layers=[(4, 64), (4, 64), (4, 64), (8, 32)], heads=4, T=24, ctx_
                 n_cand=10, top_k=4, sigma=2.0, seed=51)
 
 
+# G10: BASELINE config 2's real launch shape (SD-1.5 hooked layers, R = 128, T = 77): the reference hook + collect_maps
+# at full size; the fixture keeps per-token arg-max / sums, a strided sample and a checksum.
+FULL_CASE = dict(layers=[(16, 1280), (16, 1280), (16, 1280), (32, 640)], heads=8, T=77, ctx_dim=768, R=128, seed=71,
+                 stride=997)
+
+
 # G8/G9: the reference's driver functions on the reduced-width SD-topology model ("tiny", seed 0).
 TINY_CASE = dict(size=128, T=16, R=32, n_cand=8, top_k=4, sigma=2.0, seed=61, aug_iters=3, upscale=64)
 

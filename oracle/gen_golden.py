@@ -162,6 +162,21 @@ def main():
         g3[f"fps_ns{ns}"] = fps.numpy()
     np.savez_compressed(os.path.join(OUT, "g3_selection.npz"), **g3)
 
+    # ---------------- G3b: the 'entropy' strategy (ptp_utils.entropy_sort) -------------
+    g3b = {}
+    ent_top = ptp_utils.entropy_sort(maps, s["n_cand"])
+    g3b["entropy_sort"] = ent_top.numpy()
+    sm = torch.softmax(maps.view(maps.shape[0], -1), dim=-1)
+    g3b["entropy"] = torch.distributions.Categorical(probs=sm).entropy().numpy()
+    g3b["fps_entropy"] = ptp_utils.furthest_point_sampling(maps_t, s["top_k"], ent_top).numpy()
+    # a sharper family of maps (entropies far apart) so the ranking is not decided by rounding
+    sharp_maps = torch.softmax((maps * 40.0).view(maps.shape[0], -1) * torch.linspace(0.2, 3.0, maps.shape[0])[:, None],
+                               dim=-1).view_as(maps).contiguous()
+    g3b["entropy_sort_sharp"] = ptp_utils.entropy_sort(sharp_maps, s["n_cand"]).numpy()
+    g3b["entropy_sharp"] = torch.distributions.Categorical(
+        probs=torch.softmax(sharp_maps.view(maps.shape[0], -1), dim=-1)).entropy().numpy()
+    np.savez_compressed(os.path.join(OUT, "g3b_entropy.npz"), **g3b)
+
     # ---------------- G4: losses (+ gradients) and G7: gaussian / affine ---------------
     g4 = {}
     theta = inv.RandomAffineWithInverse().create_affine_matrix(11.0, 0.87, (0.13, -0.21))
@@ -310,11 +325,40 @@ def main():
                 augment_translate=(0.1, 0.1), controllers=controllers, num_gpus=1, upscale_size=tc["upscale"])
         inv.RandomAffineWithInverse.__call__ = real_call
         kp = ref_eval.find_max_pixel(maps9) / float(tc["upscale"])
+        # max_loc_strategy == "weighted_avg" (keypoint_regressor.py:191-196 -> eval.pixel_from_weighted_avg); the
+        # reference zeroes far pixels of its argument in place, so it gets a copy
+        kp_w = ref_eval.pixel_from_weighted_avg(maps9.clone()) / float(tc["upscale"])
+        kp_w3 = ref_eval.pixel_from_weighted_avg(maps9.clone(), distance=3)
+        kp_wall = ref_eval.pixel_from_weighted_avg(maps9.clone(), distance=-1)
         g9 = {"noise": torch.cat(drawn).numpy(), "thetas": torch.cat(thetas9).numpy(), "indices": idx.numpy(),
-              "maps": maps9.numpy(), "keypoints": kp.numpy()}
+              "maps": maps9.numpy(), "keypoints": kp.numpy(), "keypoints_weighted": kp_w.numpy(),
+              "weighted_d3": kp_w3.numpy(), "weighted_all": kp_wall.numpy()}
         np.savez_compressed(os.path.join(OUT, "g9_reference_augmented_tiny.npz"), **g9)
     finally:
         torch.randn_like = real_randn_like
+
+    # ---------------- G10: full-size launch shape of BASELINE config 2 ------------------
+    from oracle.fixtures import FULL_CASE
+    fc = FULL_CASE
+    mods = [CrossAttention(Cl, fc["ctx_dim"], fc["heads"]) for (sl, Cl) in fc["layers"]]
+    for i, m in enumerate(mods):
+        load_weights_into(m, fc["seed"] + i)
+    net = Net(mods)
+    ctrl = ptp_utils.AttentionStore()
+    ptp_utils.register_attention_control(net, ctrl, feature_upsample_res=fc["R"])
+    ctx = seeded((1, fc["T"], fc["ctx_dim"]), fc["seed"] + 200)
+    with torch.no_grad():
+        for i, (m, (sl, Cl)) in enumerate(zip(mods, fc["layers"])):
+            m.forward(seeded((1, sl * sl, Cl), fc["seed"] + 100 + i), context=ctx)
+        assert len(ctrl.step_store["attn"]) == 4 and tuple(ctrl.step_store["attn"][0].shape) == (8, 128 * 128, 77)
+        mfull = optimize.collect_maps(ctrl, upsample_res=-1, layers=[0, 1, 2, 3])
+    assert tuple(mfull.shape) == (fc["T"], fc["R"], fc["R"])
+    flat = mfull.reshape(fc["T"], -1)
+    g10 = {"argmax": flat.argmax(dim=-1).numpy(), "token_sum": flat.double().sum(dim=-1).numpy(),
+           "token_max": flat.max(dim=-1).values.numpy(), "strided": mfull.reshape(-1)[:: fc["stride"]].numpy(),
+           "checksum": np.array(mfull.double().sum().item()),
+           "weighted_checksum": np.array((mfull.double().reshape(-1) * torch.linspace(0.5, 1.5, mfull.numel(), dtype=torch.float64)).sum().item())}
+    np.savez_compressed(os.path.join(OUT, "g10_full_size.npz"), **g10)
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written to", OUT, "total bytes", tot)

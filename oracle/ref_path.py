@@ -183,6 +183,38 @@ def find_top_k_gaussian(maps, top_k, sigma=3, epsilon=1e-5, num_subjects=1):
     return torch.argsort(kl, dim=-1, descending=False)[:top_k]
 
 
+def token_entropy(maps: torch.Tensor) -> torch.Tensor:
+    """ptp_utils.py:177-181: entropy of torch.distributions.Categorical(probs=softmax_spatial(map)) per token.
+    Categorical renormalises the probs and takes log(clamp(probs, eps, 1-eps)) [torch.distributions.utils
+    probs_to_logits]; entropy = -sum(probs * logits)."""
+    n, h, w = maps.shape
+    sm = torch.softmax(maps.reshape(n, h * w), dim=-1)
+    probs = sm / sm.sum(dim=-1, keepdim=True)
+    eps = torch.finfo(probs.dtype).eps
+    logits = torch.log(probs.clamp(min=eps, max=1 - eps))
+    return -(logits * probs).sum(dim=-1)
+
+
+def entropy_sort(maps, top_k, min_dist=0.05):
+    """ptp_utils.py:165-187: ascending argsort of the per-token entropy, first top_k."""
+    return torch.argsort(token_entropy(maps), dim=-1, descending=False)[:top_k]
+
+
+def pixel_from_weighted_avg(heatmaps: torch.Tensor, distance=5) -> torch.Tensor:
+    """eval.py:113-155: zero everything farther than `distance` px from the arg-max (IN PLACE, like the reference),
+    then the intensity-weighted mean (row, col) + 0.5."""
+    b, m, n = heatmaps.shape
+    x = torch.arange(0, m).float().view(1, m, 1)
+    y = torch.arange(0, n).float().view(1, 1, n)
+    if distance != -1:
+        mx = find_max_pixel(heatmaps)
+        x_max, y_max = mx[:, 0].long(), mx[:, 1].long()
+        d = torch.sqrt((x - x_max.view(b, 1, 1)) ** 2 + (y - y_max.view(b, 1, 1)) ** 2)
+        heatmaps[d > distance] = 0.0
+    norm = heatmaps / (heatmaps.sum(dim=[1, 2], keepdim=True) + 1e-6)
+    return torch.stack([(x * norm).sum(dim=[1, 2]), (y * norm).sum(dim=[1, 2])], dim=-1) + 0.5
+
+
 # ----------------------------------------------------------------------------------------
 # a9  furthest_point_sampling                                  ptp_utils.py:115-159
 # ----------------------------------------------------------------------------------------
@@ -289,19 +321,26 @@ def add_noise(latent, noise, t: int):
 # ----------------------------------------------------------------------------------------
 # a12 one image of the optimisation loop, given the two reduced maps   optimize.py:380-420
 # ----------------------------------------------------------------------------------------
-def select_tokens(attn_map, attn_map_t, furthest_point_num_samples, top_k, sigma, num_subjects=1):
-    """optimize.py:386-395 for top_k_strategy == 'gaussian'."""
-    cand = find_top_k_gaussian(attn_map, furthest_point_num_samples, sigma=sigma,
-                               num_subjects=num_subjects)
+def select_tokens(attn_map, attn_map_t, furthest_point_num_samples, top_k, sigma, num_subjects=1,
+                  top_k_strategy="gaussian"):
+    """optimize.py:382-395 (all three strategies)."""
+    if top_k_strategy == "gaussian":
+        cand = find_top_k_gaussian(attn_map, furthest_point_num_samples, sigma=sigma, num_subjects=num_subjects)
+    elif top_k_strategy == "entropy":
+        cand = entropy_sort(attn_map, furthest_point_num_samples)
+    elif top_k_strategy == "consistent":
+        cand = torch.arange(furthest_point_num_samples)
+    else:
+        raise NotImplementedError(top_k_strategy)
     return furthest_point_sampling(attn_map_t, top_k, cand)
 
 
 def image_loss(attn_map, attn_map_t, theta, index, *, furthest_point_num_samples=25, top_k=10,
                sigma=2.0, num_subjects=1, sharpening_loss_weight=100.0,
-               equivariance_attn_loss_weight=1000.0):
+               equivariance_attn_loss_weight=1000.0, top_k_strategy="gaussian"):
     """optimize.py:380-414 for one image: returns (loss, sharp, equiv, selected indices)."""
     idx = select_tokens(attn_map.detach(), attn_map_t.detach(), furthest_point_num_samples,
-                        top_k, sigma, num_subjects)
+                        top_k, sigma, num_subjects, top_k_strategy)
     sharp = sharpening_loss(attn_map[idx], sigma=sigma, num_subjects=num_subjects)
     equiv = equivariance_loss(attn_map[idx], attn_map_t[idx], theta, index)
     loss = equiv * equivariance_attn_loss_weight + sharp * sharpening_loss_weight

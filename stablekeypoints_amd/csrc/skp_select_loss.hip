@@ -15,7 +15,7 @@ struct StatsArgs { int T, R, S; float sigma, eps; };
 // ptp_utils.py:95-108 (KL against the normalised gaussian), optimize_token.py:203-241.
 __global__ __launch_bounds__(256) void skp_token_stats_kernel(const float* __restrict__ M, StatsArgs a,
                                                               int32_t* __restrict__ argmax_out,
-                                                              float* __restrict__ kl_out) {
+                                                              float* __restrict__ kl_out, float* __restrict__ ent_out) {
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     __shared__ float red[4];
@@ -55,6 +55,24 @@ __global__ __launch_bounds__(256) void skp_token_stats_kernel(const float* __res
         }
         if (j == 0) maxval0 = bv;
         __syncthreads();
+    }
+    if (ent_out) {
+        // ptp_utils.py:165-187 entropy_sort: p = softmax_{R*R}(M[t]) (no epsilon), then torch's Categorical(probs=p):
+        // probs = p / sum(p), logits = log(clamp(probs, eps, 1-eps)) with eps = FLT_EPSILON, H = -sum probs*logits.
+        float se0 = 0.f;
+        for (int p = tid; p < RR; p += 256) se0 += expf(m[p] - maxval0);
+        se0 = skp_block_sum_256(se0, red);
+        float sp = 0.f;
+        for (int p = tid; p < RR; p += 256) sp += expf(m[p] - maxval0) / se0;
+        sp = skp_block_sum_256(sp, red);
+        float h = 0.f;
+        for (int p = tid; p < RR; p += 256) {
+            const float pr = (expf(m[p] - maxval0) / se0) / sp;
+            const float cl = fminf(fmaxf(pr, 1.1920928955078125e-07f), 1.0f - 1.1920928955078125e-07f);
+            h += pr * logf(cl);
+        }
+        h = skp_block_sum_256(h, red);
+        if (tid == 0) ent_out[t] = -h;
     }
     if (!kl_out) return;
     // gaussian centres in pixels: (loc / R) * R, fp32 like the reference (ptp_utils.py:97, optimize_token.py:210)
@@ -98,11 +116,11 @@ __global__ __launch_bounds__(256) void skp_token_stats_kernel(const float* __res
 }
 
 extern "C" int skp_token_stats_f32(const float* M, int T, int R, int num_subjects, float sigma, float eps,
-                                   int32_t* argmax, float* kl, void* stream) {
+                                   int32_t* argmax, float* kl, float* entropy, void* stream) {
     if (!M || !argmax || T <= 0 || R <= 0) return SKP_E_BADARG;
     if (num_subjects < 1 || num_subjects > SKP_MAX_SUBJECTS || R > 4096) return SKP_E_RANGE;
     StatsArgs a{T, R, num_subjects, sigma, eps};
-    hipLaunchKernelGGL(skp_token_stats_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, M, a, argmax, kl);
+    hipLaunchKernelGGL(skp_token_stats_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, M, a, argmax, kl, entropy);
     return skp_launch_status();
 }
 
@@ -127,12 +145,17 @@ __global__ __launch_bounds__(256) void skp_select_kernel(const float* __restrict
     const int tid = threadIdx.x;
     for (int i = tid; i < T; i += 256) s_kl[i] = kl[i];
     __syncthreads();
-    for (int i = tid; i < T; i += 256) {                        // rank by (kl asc, index asc)
+    // rank by (value asc, index asc) with NaN ordered after every number (torch.argsort puts NaN last): the ranks
+    // form a permutation of 0..T-1 for ANY input, so every candidate slot is written exactly once
+    for (int i = tid; i < T; i += 256) {
         const float v = s_kl[i];
+        const bool vn = v != v;
         int rank = 0;
         for (int j = 0; j < T; ++j) {
             const float u = s_kl[j];
-            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+            const bool un = u != u;
+            const bool before = (un != vn) ? vn : (un ? (j < i) : (u < v || (u == v && j < i)));
+            rank += before ? 1 : 0;
         }
         if (rank < n_cand) s_cand[rank] = i;
     }
@@ -208,11 +231,33 @@ struct LossArgs {
     float th[6];                                                // inverse affine, row-major 2x3
 };
 
+// Bilinear sample position of output pixel (col,row) in the transformed map: affine_grid + grid_sample with
+// align_corners=False (invertable_transform.py:72-92).  Explicitly rounded ops: the loss kernel and the gradient gather
+// below must agree bit for bit on the footprint of every pixel.
+struct SkpBilin { int x0, y0; float wx0, wx1, wy0, wy1; };
+__device__ __forceinline__ SkpBilin skp_bilin(const LossArgs& a, int col, int row) {
+    const float Rf = (float)a.R;
+    const float xs = __fsub_rn(__fdiv_rn(__fadd_rn(__fmul_rn(2.0f, (float)col), 1.0f), Rf), 1.0f);
+    const float ys = __fsub_rn(__fdiv_rn(__fadd_rn(__fmul_rn(2.0f, (float)row), 1.0f), Rf), 1.0f);
+    const float gx = __fadd_rn(__fadd_rn(__fmul_rn(a.th[0], xs), __fmul_rn(a.th[1], ys)), a.th[2]);
+    const float gy = __fadd_rn(__fadd_rn(__fmul_rn(a.th[3], xs), __fmul_rn(a.th[4], ys)), a.th[5]);
+    const float fx = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), Rf), 1.0f), 0.5f);
+    const float fy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), Rf), 1.0f), 0.5f);
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    SkpBilin b;
+    // clamp before the int conversion so a diverged affine cannot overflow it (every clamped value is out of range)
+    b.x0 = (int)fminf(fmaxf(x0f, -2.0f), Rf + 1.0f);
+    b.y0 = (int)fminf(fmaxf(y0f, -2.0f), Rf + 1.0f);
+    b.wx1 = __fsub_rn(fx, x0f); b.wx0 = __fsub_rn(1.0f, b.wx1);
+    b.wy1 = __fsub_rn(fy, y0f); b.wy0 = __fsub_rn(1.0f, b.wy1);
+    return b;
+}
+
 __global__ __launch_bounds__(256) void skp_losses_kernel(const float* __restrict__ M, const float* __restrict__ Mt,
                                                          const int64_t* __restrict__ sel,
                                                          const int32_t* __restrict__ argmax, LossArgs a,
                                                          float* __restrict__ partial, float* __restrict__ g_sharp,
-                                                         float* __restrict__ g_eq_a, float* __restrict__ g_eq_b) {
+                                                         float* __restrict__ g_eq_a) {
     __shared__ float red[4];
     const int k = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int R = a.R, RR = R * R;
@@ -244,30 +289,17 @@ __global__ __launch_bounds__(256) void skp_losses_kernel(const float* __restrict
         ss += ds * ds;
         g_sharp[(size_t)k * RR + p] = gscale * ds;
         // --- equivariance: bilinear sample of the transformed map through the inverse affine
-        const float xs = (2.0f * (float)col + 1.0f) / (float)R - 1.0f;
-        const float ys = (2.0f * (float)row + 1.0f) / (float)R - 1.0f;
-        const float gx = a.th[0] * xs + a.th[1] * ys + a.th[2];
-        const float gy = a.th[3] * xs + a.th[4] * ys + a.th[5];
-        const float fx = ((gx + 1.0f) * (float)R - 1.0f) * 0.5f;
-        const float fy = ((gy + 1.0f) * (float)R - 1.0f) * 0.5f;
-        const float x0f = floorf(fx), y0f = floorf(fy);
-        const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-        const float wx1 = fx - x0f, wx0 = 1.0f - wx1, wy1 = fy - y0f, wy0 = 1.0f - wy1;
+        const SkpBilin bl = skp_bilin(a, col, row);
+        const int x0 = bl.x0, y0 = bl.y0, x1 = x0 + 1, y1 = y0 + 1;
         const bool vx0 = x0 >= 0 && x0 < R, vx1 = x1 >= 0 && x1 < R, vy0 = y0 >= 0 && y0 < R, vy1 = y1 >= 0 && y1 < R;
         float sval = 0.f;
-        if (vy0 && vx0) sval += mt[y0 * R + x0] * (wy0 * wx0);
-        if (vy0 && vx1) sval += mt[y0 * R + x1] * (wy0 * wx1);
-        if (vy1 && vx0) sval += mt[y1 * R + x0] * (wy1 * wx0);
-        if (vy1 && vx1) sval += mt[y1 * R + x1] * (wy1 * wx1);
+        if (vy0 && vx0) sval += mt[y0 * R + x0] * __fmul_rn(bl.wy0, bl.wx0);
+        if (vy0 && vx1) sval += mt[y0 * R + x1] * __fmul_rn(bl.wy0, bl.wx1);
+        if (vy1 && vx0) sval += mt[y1 * R + x0] * __fmul_rn(bl.wy1, bl.wx0);
+        if (vy1 && vx1) sval += mt[y1 * R + x1] * __fmul_rn(bl.wy1, bl.wx1);
         const float de = v - sval;
         se += de * de;
-        const float ge = gscale * de;
-        g_eq_a[(size_t)k * RR + p] = ge;
-        float* gb = g_eq_b + (size_t)k * RR;
-        if (vy0 && vx0) atomicAdd(&gb[y0 * R + x0], -ge * (wy0 * wx0));
-        if (vy0 && vx1) atomicAdd(&gb[y0 * R + x1], -ge * (wy0 * wx1));
-        if (vy1 && vx0) atomicAdd(&gb[y1 * R + x0], -ge * (wy1 * wx0));
-        if (vy1 && vx1) atomicAdd(&gb[y1 * R + x1], -ge * (wy1 * wx1));
+        g_eq_a[(size_t)k * RR + p] = gscale * de;
     }
     ss = skp_block_sum_256(ss, red);
     se = skp_block_sum_256(se, red);
@@ -275,6 +307,49 @@ __global__ __launch_bounds__(256) void skp_losses_kernel(const float* __restrict
         partial[(size_t)(0 * a.K + k) * a.nchunk + chunk] = ss;
         partial[(size_t)(1 * a.K + k) * a.nchunk + chunk] = se;
     }
+}
+
+// d equiv / d Mt[sel[k]] as a GATHER (no atomics => bit-reproducible): source pixel (sx,sy) of the transformed map
+// collects -g_eq_a[p] * w(p -> s) from every output pixel p whose bilinear footprint contains it.  Those p lie in the
+// pre-image of the box (sx-1,sx+1) x (sy-1,sy+1) under the affine pixel map; its bounding box (+1 pixel of slack for
+// rounding) is scanned in row-major order and each candidate's footprint is recomputed with skp_bilin.
+__global__ __launch_bounds__(256) void skp_equiv_grad_kernel(LossArgs a, const float* __restrict__ g_eq_a,
+                                                            float* __restrict__ g_eq_b) {
+    const int k = blockIdx.y, R = a.R, RR = R * R;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= RR) return;
+    const int sy = s / R, sx = s - sy * R;
+    // pixel map: f = A (c + 0.5) + o,  A = [[th0,th1],[th3,th4]],  o = R/2 (t + 1 - rowsum(A)) - 0.5
+    const float a00 = a.th[0], a01 = a.th[1], a10 = a.th[3], a11 = a.th[4];
+    const float ox = 0.5f * (float)R * (a.th[2] + 1.0f - a00 - a01) - 0.5f;
+    const float oy = 0.5f * (float)R * (a.th[5] + 1.0f - a10 - a11) - 0.5f;
+    const float det = a00 * a11 - a01 * a10;
+    int c0 = 0, c1 = R - 1, r0 = 0, r1 = R - 1;
+    if (fabsf(det) > 1e-12f) {
+        const float i00 = a11 / det, i01 = -a01 / det, i10 = -a10 / det, i11 = a00 / det;
+        float cmin = INFINITY, cmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float fx = (float)sx + ((q & 1) ? 1.0f : -1.0f) - ox, fy = (float)sy + ((q & 2) ? 1.0f : -1.0f) - oy;
+            const float c = i00 * fx + i01 * fy - 0.5f, r = i10 * fx + i11 * fy - 0.5f;
+            cmin = fminf(cmin, c); cmax = fmaxf(cmax, c); rmin = fminf(rmin, r); rmax = fmaxf(rmax, r);
+        }
+        if (cmin == cmin && cmax == cmax && rmin == rmin && rmax == rmax) {     // NaN => scan everything
+            c0 = (int)fmaxf(floorf(cmin) - 1.0f, 0.0f); c1 = (int)fminf(ceilf(cmax) + 1.0f, (float)(R - 1));
+            r0 = (int)fmaxf(floorf(rmin) - 1.0f, 0.0f); r1 = (int)fminf(ceilf(rmax) + 1.0f, (float)(R - 1));
+        }
+    }
+    const float* ga = g_eq_a + (size_t)k * RR;
+    float acc = 0.f;
+    for (int row = r0; row <= r1; ++row)
+        for (int col = c0; col <= c1; ++col) {
+            const SkpBilin bl = skp_bilin(a, col, row);
+            const float wx = (bl.x0 == sx) ? bl.wx0 : ((bl.x0 + 1 == sx) ? bl.wx1 : 0.f);
+            const float wy = (bl.y0 == sy) ? bl.wy0 : ((bl.y0 + 1 == sy) ? bl.wy1 : 0.f);
+            const bool hit = (bl.x0 == sx || bl.x0 + 1 == sx) && (bl.y0 == sy || bl.y0 + 1 == sy);
+            if (hit) acc -= ga[row * R + col] * __fmul_rn(wy, wx);
+        }
+    g_eq_b[(size_t)k * RR + s] = acc;
 }
 
 extern "C" int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
@@ -288,7 +363,11 @@ extern "C" int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t
     a.nchunk = (R * R + 1023) / 1024;
     for (int i = 0; i < 6; ++i) a.th[i] = theta_inv[i];
     hipLaunchKernelGGL(skp_losses_kernel, dim3(a.nchunk, K), dim3(256), 0, (hipStream_t)stream, M, Mt, sel, argmax, a,
-                       partial, g_sharp, g_eq_a, g_eq_b);
+                       partial, g_sharp, g_eq_a);
+    int rc = skp_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(skp_equiv_grad_kernel, dim3((R * R + 255) / 256, K), dim3(256), 0, (hipStream_t)stream, a, g_eq_a,
+                       g_eq_b);
     return skp_launch_status();
 }
 
@@ -314,4 +393,4 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 12; }
+extern "C" int skp_abi_version(void) { return 13; }

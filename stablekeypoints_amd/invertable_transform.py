@@ -20,6 +20,7 @@ class RandomAffineWithInverse:
         self.scale = scale
         self.translate = translate
         self.last_params = {"theta": torch.eye(2, 3).unsqueeze(0)}
+        self.last_theta_host = self.last_params["theta"]     # host copy of last_params["theta"] (None if unknown)
 
     def create_affine_matrix(self, angle, scale, translations_percent):
         a = math.radians(angle)
@@ -41,6 +42,9 @@ class RandomAffineWithInverse:
     def __call__(self, img_tensor, theta=None):
         if theta is None:
             theta = self.sample_theta(img_tensor.shape[0])
+        # thetas are drawn (or handed in) on the host: keep that copy so consumers that need the numbers on the host
+        # (the loss kernel takes the inverse affine as launch arguments) never read them back from the device
+        self.last_theta_host = theta.detach() if theta.device.type == "cpu" else None
         theta = theta.to(img_tensor.device)
         self.last_params = {"theta": theta}
         grid = F.affine_grid(theta, img_tensor.size(), align_corners=False)

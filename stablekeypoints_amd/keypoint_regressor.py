@@ -9,7 +9,7 @@ from . import dist as skp_dist
 from . import ops, ptp_utils
 from ._maps import collect_maps_batched
 from .eval import find_max_pixel, pixel_from_weighted_avg
-from .optimize import build_dataset
+from .optimize import build_dataset, token_order
 
 
 @torch.no_grad()
@@ -32,11 +32,10 @@ def find_best_indices(ldm, context, args, controllers, num_gpus, from_where=["do
                                   early_exit=True, controllers={dev: controller})
         maps = collect_maps_batched(controller, layers=args.layers)
         for i in range(n):
-            am, kl = ops.token_stats(maps[i], num_subjects=getattr(args, "num_subjects", 1), sigma=args.sigma)
+            am, order = token_order(maps[i], getattr(args, "top_k_strategy", "gaussian"),
+                                    getattr(args, "num_subjects", 1), args.sigma)
             n_cand = min(args.furthest_point_num_samples, maps.shape[1])
-            if getattr(args, "top_k_strategy", "gaussian") == "consistent":
-                kl = torch.arange(maps.shape[1], device=dev, dtype=torch.float32)
-            _, sel = ops.select_tokens(kl, am[0], maps.shape[-1], n_cand, args.top_k)
+            _, sel = ops.select_tokens(order, am[0], maps.shape[-1], n_cand, args.top_k)
             picked.append(sel)
         done += n
     picked = torch.cat(picked)

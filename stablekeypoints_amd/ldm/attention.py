@@ -92,21 +92,33 @@ class BasicTransformerBlock(nn.Module):
 
 
 class Transformer2DModel(nn.Module):
-    def __init__(self, heads: int, dim_head: int, in_channels: int, cross_attention_dim: int, groups: int = 32):
+    """`depth` transformer blocks between a projection in and out.  SD-1.x: depth 1, 1x1-conv projections (0.8.0);
+    SD-2.x / SDXL: `use_linear_projection` (nn.Linear over tokens) and, for SDXL, depth 2 / 10 [3P]."""
+
+    def __init__(self, heads: int, dim_head: int, in_channels: int, cross_attention_dim: int, groups: int = 32,
+                 depth: int = 1, use_linear_projection: bool = False):
         super().__init__()
         inner = heads * dim_head
+        self.use_linear_projection = use_linear_projection
         self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6, affine=True)
-        self.proj_in = nn.Conv2d(in_channels, inner, 1)
-        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
-        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+        self.proj_in = nn.Linear(in_channels, inner) if use_linear_projection else nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)
+                                                 for _ in range(depth)])
+        self.proj_out = nn.Linear(inner, in_channels) if use_linear_projection else nn.Conv2d(inner, in_channels, 1)
 
     def forward(self, x, context=None):
         b, c, hh, ww = x.shape
         res = x
-        h = self.proj_in(self.norm(x))
-        h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, h.shape[1])
+        h = self.norm(x)
+        if self.use_linear_projection:
+            h = self.proj_in(h.permute(0, 2, 3, 1).reshape(b, hh * ww, c))
+        else:
+            h = self.proj_in(h)
+            h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, h.shape[1])
         for blk in self.transformer_blocks:
             h = blk(h, context=context)
+        if self.use_linear_projection:
+            return self.proj_out(h).reshape(b, hh, ww, -1).permute(0, 3, 1, 2) + res
         h = h.reshape(b, hh, ww, -1).permute(0, 3, 1, 2)
         return self.proj_out(h) + res
 

@@ -89,10 +89,11 @@ class Upsample2D(nn.Module):
 
 
 class CrossAttnDownBlock2D(nn.Module):
-    def __init__(self, in_ch, out_ch, temb_ch, heads, ctx_dim, num_layers=2, add_downsample=True):
+    def __init__(self, in_ch, out_ch, temb_ch, heads, ctx_dim, num_layers=2, add_downsample=True, depth=1, linear_proj=False):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock2D(in_ch if i == 0 else out_ch, out_ch, temb_ch) for i in range(num_layers)])
-        self.attentions = nn.ModuleList([Transformer2DModel(heads, out_ch // heads, out_ch, ctx_dim) for _ in range(num_layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, out_ch // heads, out_ch, ctx_dim, depth=depth,
+                                                            use_linear_projection=linear_proj) for _ in range(num_layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_ch)]) if add_downsample else None
 
     def forward(self, h, temb, ctx):
@@ -124,9 +125,10 @@ class DownBlock2D(nn.Module):
 
 
 class UNetMidBlock2DCrossAttn(nn.Module):
-    def __init__(self, ch, temb_ch, heads, ctx_dim):
+    def __init__(self, ch, temb_ch, heads, ctx_dim, depth=1, linear_proj=False):
         super().__init__()
-        self.attentions = nn.ModuleList([Transformer2DModel(heads, ch // heads, ch, ctx_dim)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, ch // heads, ch, ctx_dim, depth=depth,
+                                                            use_linear_projection=linear_proj)])
         self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb_ch), ResnetBlock2D(ch, ch, temb_ch)])
 
     def forward(self, h, temb, ctx):
@@ -154,14 +156,16 @@ class UpBlock2D(nn.Module):
 
 
 class CrossAttnUpBlock2D(nn.Module):
-    def __init__(self, in_ch, prev_ch, out_ch, temb_ch, heads, ctx_dim, num_layers=3, add_upsample=True):
+    def __init__(self, in_ch, prev_ch, out_ch, temb_ch, heads, ctx_dim, num_layers=3, add_upsample=True, depth=1,
+                 linear_proj=False):
         super().__init__()
         res = []
         for i in range(num_layers):
             skip = in_ch if i == num_layers - 1 else out_ch
             res.append(ResnetBlock2D((prev_ch if i == 0 else out_ch) + skip, out_ch, temb_ch))
         self.resnets = nn.ModuleList(res)
-        self.attentions = nn.ModuleList([Transformer2DModel(heads, out_ch // heads, out_ch, ctx_dim) for _ in range(num_layers)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, out_ch // heads, out_ch, ctx_dim, depth=depth,
+                                                            use_linear_projection=linear_proj) for _ in range(num_layers)])
         self.upsamplers = nn.ModuleList([Upsample2D(out_ch)]) if add_upsample else None
 
     def forward(self, h, skips, temb, ctx):
@@ -172,37 +176,60 @@ class CrossAttnUpBlock2D(nn.Module):
         return h
 
 
+def _per_block(v, n):
+    return [int(v)] * n if isinstance(v, int) else [int(x) for x in v]
+
+
 class UNet2DConditionModel(nn.Module):
+    """SD-1.x by default.  SD-2.x: `attention_head_dim=(5,10,20,20)` (head COUNT per block, 64-wide heads),
+    `cross_attention_dim=1024`, `use_linear_projection=True`.  SDXL-base: three blocks (320,640,1280) with
+    `transformer_layers_per_block=(1,2,10)`, heads (5,10,20), `cross_attention_dim=2048` and the
+    `addition_embed_type="text_time"` micro-conditioning branch (pooled text embedding + 6 size/crop ids) [3P]."""
+
     def __init__(self, in_channels=4, out_channels=4, block_out_channels: Sequence[int] = (320, 640, 1280, 1280),
                  layers_per_block=2, attention_head_dim=8, cross_attention_dim=768,
                  down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
-                 up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")):
+                 up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+                 transformer_layers_per_block=1, use_linear_projection=False, addition_embed_type=None,
+                 addition_time_embed_dim=None, projection_class_embeddings_input_dim=None):
         super().__init__()
         boc = list(block_out_channels)
+        nb = len(boc)
         temb = boc[0] * 4
-        heads = attention_head_dim                     # 0.8.0: `attention_head_dim` is the head COUNT [3P]
-        self.config = dict(in_channels=in_channels, block_out_channels=tuple(boc), cross_attention_dim=cross_attention_dim)
+        heads = _per_block(attention_head_dim, nb)     # 0.8.0: `attention_head_dim` is the head COUNT [3P]
+        depth = _per_block(transformer_layers_per_block, nb)
+        lin = bool(use_linear_projection)
+        self.config = dict(in_channels=in_channels, block_out_channels=tuple(boc), cross_attention_dim=cross_attention_dim,
+                           addition_embed_type=addition_embed_type)
         self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
         self.time_embedding = TimestepEmbedding(boc[0], temb)
         self._t_dim = boc[0]
+        self.add_embedding = None
+        if addition_embed_type == "text_time":
+            self._add_t_dim = int(addition_time_embed_dim)
+            self.add_embedding = TimestepEmbedding(int(projection_class_embeddings_input_dim), temb)
+        elif addition_embed_type is not None:
+            raise NotImplementedError(addition_embed_type)
         downs, ch = [], boc[0]
         for i, kind in enumerate(down_block_types):
-            last = i == len(boc) - 1
+            last = i == nb - 1
             if kind == "CrossAttnDownBlock2D":
-                downs.append(CrossAttnDownBlock2D(ch, boc[i], temb, heads, cross_attention_dim, layers_per_block, not last))
+                downs.append(CrossAttnDownBlock2D(ch, boc[i], temb, heads[i], cross_attention_dim, layers_per_block, not last,
+                                                  depth=depth[i], linear_proj=lin))
             else:
                 downs.append(DownBlock2D(ch, boc[i], temb, layers_per_block, not last))
             ch = boc[i]
         self.down_blocks = nn.ModuleList(downs)
-        self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], temb, heads, cross_attention_dim)
-        ups, rev = [], boc[::-1]
+        self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], temb, heads[-1], cross_attention_dim, depth=depth[-1], linear_proj=lin)
+        ups, rev, rheads, rdepth = [], boc[::-1], heads[::-1], depth[::-1]
         prev = rev[0]
         for i, kind in enumerate(up_block_types):
             out_ch = rev[i]
-            in_ch = rev[min(i + 1, len(boc) - 1)]
-            last = i == len(boc) - 1
+            in_ch = rev[min(i + 1, nb - 1)]
+            last = i == nb - 1
             if kind == "CrossAttnUpBlock2D":
-                ups.append(CrossAttnUpBlock2D(in_ch, prev, out_ch, temb, heads, cross_attention_dim, layers_per_block + 1, not last))
+                ups.append(CrossAttnUpBlock2D(in_ch, prev, out_ch, temb, rheads[i], cross_attention_dim, layers_per_block + 1,
+                                              not last, depth=rdepth[i], linear_proj=lin))
             else:
                 ups.append(UpBlock2D(in_ch, prev, out_ch, temb, layers_per_block + 1, not last))
             prev = out_ch
@@ -210,11 +237,25 @@ class UNet2DConditionModel(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, boc[0], eps=1e-5)
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
 
-    def forward(self, sample, timestep, encoder_hidden_states):
+    def default_added_cond(self, sample):
+        """SDXL micro-conditioning when the caller gives none: zero pooled text embedding (no text encoder on this path)
+        and time_ids = (orig_h, orig_w, crop_top, crop_left, target_h, target_w) of the un-cropped input image."""
+        b = sample.shape[0]
+        hh, ww = float(sample.shape[-2] * 8), float(sample.shape[-1] * 8)
+        pooled = self.add_embedding.linear_1.in_features - 6 * self._add_t_dim
+        return {"text_embeds": torch.zeros(b, pooled, device=sample.device, dtype=sample.dtype),
+                "time_ids": torch.tensor([[hh, ww, 0.0, 0.0, hh, ww]], device=sample.device, dtype=sample.dtype).expand(b, -1)}
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=sample.device)
         timestep = timestep.reshape(-1).to(sample.device).expand(sample.shape[0])
         temb = self.time_embedding(timestep_embedding(timestep, self._t_dim).to(sample.dtype))
+        if self.add_embedding is not None:
+            cond = added_cond_kwargs if added_cond_kwargs is not None else self.default_added_cond(sample)
+            ids = cond["time_ids"]
+            tids = timestep_embedding(ids.reshape(-1), self._add_t_dim).reshape(ids.shape[0], -1)
+            temb = temb + self.add_embedding(torch.cat([cond["text_embeds"], tids.to(sample.dtype)], dim=-1))
         h = self.conv_in(sample)
         skips = [h]
         for blk in self.down_blocks:

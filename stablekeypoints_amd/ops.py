@@ -205,18 +205,20 @@ def materialize_probs(q: torch.Tensor, k: torch.Tensor, heads: int, scale: float
 # token statistics / selection                      eval.py:39-111, ptp_utils.py:86-159
 # ---------------------------------------------------------------------------------------------
 def token_stats(M: torch.Tensor, num_subjects: int = 1, sigma: float = 2.0, eps: float = 1e-5,
-                want_kl: bool = True):
-    """-> (argmax int32 [num_subjects, T] flat indices, kl float32 [T] or None)."""
+                want_kl: bool = True, want_entropy: bool = False):
+    """-> (argmax int32 [num_subjects, T] flat indices, kl float32 [T] or None[, entropy float32 [T]])."""
     M = _dev(M.detach(), "M")
     T, R, R2 = M.shape
     if R != R2:
         raise RuntimeError("token_stats: map must be square")
     am = torch.empty(num_subjects, T, device=M.device, dtype=torch.int32)
     kl = torch.empty(T, device=M.device, dtype=torch.float32) if want_kl else None
+    ent = torch.empty(T, device=M.device, dtype=torch.float32) if want_entropy else None
     N.check(N.lib().skp_token_stats_f32(M.data_ptr(), T, R, num_subjects, float(sigma), float(eps),
-                                        am.data_ptr(), kl.data_ptr() if want_kl else None, _stream()),
+                                        am.data_ptr(), kl.data_ptr() if want_kl else None,
+                                        ent.data_ptr() if want_entropy else None, _stream()),
             "skp_token_stats_f32")
-    return am, kl
+    return (am, kl, ent) if want_entropy else (am, kl)
 
 
 def select_tokens(kl: torch.Tensor, argmax_t: torch.Tensor, R: int, n_cand: int, top_k: int):
@@ -254,7 +256,7 @@ class LossesFn(torch.autograd.Function):
         partial = torch.empty(2, K, nchunk, device=M.device, dtype=torch.float32)
         g_sharp = torch.empty(K, R, R, device=M.device, dtype=torch.float32)
         g_eq_a = torch.empty_like(g_sharp)
-        g_eq_b = torch.zeros_like(g_sharp)
+        g_eq_b = torch.empty_like(g_sharp)
         th, _keep = N.float_array(theta_inv)
         N.check(N.lib().skp_losses_fwd_f32(M.data_ptr(), Mt.data_ptr(), sel.data_ptr(), K, T, R, argmax.data_ptr(),
                                            int(num_subjects), float(sigma), th, partial.data_ptr(),
@@ -470,7 +472,8 @@ def _wino_filters(weight, backward):
     """Transformed filter of a frozen weight, built once per (weight storage, version) and kept resident."""
     key = "_skp_wino_bwd" if backward else "_skp_wino_fwd"
     hit = getattr(weight, key, None)
-    if hit is not None and hit[0] == weight._version and hit[1].device == weight.device:
+    tag = (weight._version, weight.data_ptr())       # data_ptr: `weight.data = ...` / load_state_dict(assign=True)
+    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
         return hit[1]
     w = _dev(weight.detach(), "weight")
     co, ci = w.shape[:2]
@@ -479,7 +482,7 @@ def _wino_filters(weight, backward):
         N.check(N.lib().skp_conv3x3_filter_f32(w.data_ptr(), U.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_filter_f32")
     else:
         N.check(N.lib().skp_conv3x3_filter_f32(w.data_ptr(), U.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_filter_f32")
-    setattr(weight, key, (weight._version, U))
+    setattr(weight, key, (tag, U))
     return U
 
 
@@ -499,7 +502,8 @@ def _wino4_filters(weight, backward):
     """F(4x4,3x3) transformed filter of a frozen weight (36*Cin*Cout floats), built once and kept resident."""
     key = "_skp_wino4_bwd" if backward else "_skp_wino4_fwd"
     hit = getattr(weight, key, None)
-    if hit is not None and hit[0] == weight._version and hit[1].device == weight.device:
+    tag = (weight._version, weight.data_ptr())
+    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
         return hit[1]
     w = _dev(weight.detach(), "weight")
     co, ci = w.shape[:2]
@@ -508,7 +512,7 @@ def _wino4_filters(weight, backward):
         N.check(N.lib().skp_conv3x3_f4_filter_f32(w.data_ptr(), U.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_f4_filter_f32")
     else:
         N.check(N.lib().skp_conv3x3_f4_filter_f32(w.data_ptr(), U.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_f4_filter_f32")
-    setattr(weight, key, (weight._version, U))
+    setattr(weight, key, (tag, U))
     return U
 
 
@@ -589,13 +593,16 @@ class Conv3x3Fn(torch.autograd.Function):
 def conv3x3(x, weight, bias=None, residual=None):
     if not conv3x3_supported(x.shape, weight.shape):
         raise ValueError(f"conv3x3: unsupported shape x {tuple(x.shape)} w {tuple(weight.shape)}")
+    if weight.requires_grad or (bias is not None and bias.requires_grad):
+        raise ValueError("conv3x3: the Winograd kernels serve FROZEN weights only (no weight/bias gradient)")
     return Conv3x3Fn.apply(x, weight, bias, residual)
 
 
 def conv3x3_auto(x, weight, bias=None, residual=None):
     """The frozen blocks' 3x3 convolution (+ bias + residual): Winograd kernel where it is wanted, library
     convolution (and the fused bias+residual pass) otherwise."""
-    if x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
+    frozen = not (weight.requires_grad or (bias is not None and bias.requires_grad))     # the kernels give no dW / db
+    if frozen and x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
         return Conv3x3Fn.apply(x, weight, bias, residual)
     if residual is None:
         return torch.nn.functional.conv2d(x, weight, bias, padding=1)

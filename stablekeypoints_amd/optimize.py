@@ -98,18 +98,27 @@ def image_losses(attn_map, attn_map_t, theta_row, args):
     """optimize.py:380-414 for one image, entirely on device: -> (sharp, equiv, selected tokens)."""
     sigma, ns = args.sigma, getattr(args, "num_subjects", 1)
     strategy = getattr(args, "top_k_strategy", "gaussian")
-    am, kl = ops.token_stats(attn_map, num_subjects=ns, sigma=sigma, want_kl=(strategy == "gaussian"))
+    am, order = token_order(attn_map, strategy, ns, sigma)
     am_t, _ = ops.token_stats(attn_map_t, num_subjects=1, sigma=sigma, want_kl=False)
-    if strategy == "gaussian":
-        order = kl
-    elif strategy == "consistent":
-        order = torch.arange(attn_map.shape[0], device=attn_map.device, dtype=torch.float32)
-    else:
-        raise NotImplementedError(strategy)
     n_cand = min(args.furthest_point_num_samples, attn_map.shape[0])
     _, sel = ops.select_tokens(order, am_t[0], attn_map.shape[-1], n_cand, args.top_k)
     sharp, equiv = ops.fused_losses(attn_map, attn_map_t, sel, am, theta_row, sigma, ns)
     return sharp, equiv, sel
+
+
+def token_order(attn_map, strategy, num_subjects, sigma):
+    """Per-token score whose ascending order gives the candidate tokens (optimize.py:382-393):
+    'gaussian' = KL to the gaussian target (ptp_utils.py:86-112), 'entropy' = entropy of the softmax-normalised map
+    (ptp_utils.py:165-187), 'consistent' = the token index.  -> (argmax i32 [num_subjects,T], score f32 [T])."""
+    if strategy == "gaussian":
+        return ops.token_stats(attn_map, num_subjects=num_subjects, sigma=sigma, want_kl=True)
+    if strategy == "entropy":
+        am, _, ent = ops.token_stats(attn_map, num_subjects=num_subjects, sigma=sigma, want_kl=False, want_entropy=True)
+        return am, ent
+    if strategy == "consistent":
+        am, _ = ops.token_stats(attn_map, num_subjects=num_subjects, sigma=sigma, want_kl=False)
+        return am, torch.arange(attn_map.shape[0], device=attn_map.device, dtype=torch.float32)
+    raise NotImplementedError(strategy)
 
 
 def group_step(ldm, images, context, args, controller, transform, denom, noise=None, thetas=None):
@@ -119,7 +128,9 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
     dev = context.device
     images = images.to(dev)
     warped = transform(images, theta=thetas)                     # draws n thetas (4 uniforms each) unless given
-    thetas = transform.last_params["theta"].detach().cpu()
+    thetas = transform.last_theta_host                           # host copy: no device read-back
+    if thetas is None:
+        thetas = transform.last_params["theta"].detach().cpu()   # caller passed device thetas
     both = torch.cat([images, warped], dim=0)
     ptp_utils.find_pred_noise(ldm, both, context, noise_level=args.noise_level, device=dev, noise=noise,
                               early_exit=True, controllers={dev: controller})
@@ -150,7 +161,8 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
     transform = RandomAffineWithInverse(degrees=args.augment_degrees, scale=args.augment_scale,
                                         translate=args.augment_translate)
     if context is None:
-        context = ptp_utils.init_random_noise(args.device, num_words=args.num_tokens)
+        context = ptp_utils.init_random_noise(args.device, num_words=args.num_tokens,
+                                              dim=ldm.unet.config.get("cross_attention_dim", 768))
     context = context.to(dev)
     context.requires_grad = True
     optimizer = torch.optim.Adam([context], lr=args.lr)
@@ -177,6 +189,8 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
             running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size))
             done += n
         reducer.step()
+        if log_every and (step + 1) % log_every == 0:
+            skp_dist.allreduce_sum_(running)                     # every rank holds its share of the batch mean
         if log_every and (step + 1) % log_every == 0 and rank == 0:
             r = running.tolist()
             print(f"step {step + 1}: loss {r[0]:.6f} equivariance {r[1] * args.equivariance_attn_loss_weight:.6f} "

@@ -129,6 +129,11 @@ def register_attention_control(model, controller, feature_upsample_res=256):
                 stop = getattr(controller, "stop_after", None)
                 if stop is not None and len(controller.step_store["attn"]) >= stop:
                     raise StopForward()
+            elif (is_cross and sequence_length > MAX_STORED_SEQ and controller.step_store["attn"]
+                  and getattr(controller, "stop_after", None) is not None):
+                # only `up` blocks are hooked and their resolution never decreases: once a cross layer is past the
+                # 32^2 gate no later layer can store (SD-2.x at 768^2 stores 3 layers, not 4) => nothing left to record
+                raise StopForward()
             return to_out(out)
 
         return forward
@@ -257,5 +262,16 @@ def furthest_point_sampling(attention_maps, top_k, top_initial_candidates):
     return sel
 
 
-def init_random_noise(device, num_words=77):
-    return torch.randn(1, num_words, 768).to(device)
+def entropy_sort(attention_maps, top_k, min_dist=0.05):
+    """ptp_utils.py:165-187 -> int64[top_k] (device): tokens by ascending entropy of softmax_{R*R}(map)."""
+    _, _, ent = ops.token_stats(attention_maps, num_subjects=1, want_kl=False, want_entropy=True)
+    n = attention_maps.shape[0]
+    top_k = min(int(top_k), n)
+    am = torch.zeros(n, device=attention_maps.device, dtype=torch.int32)
+    cand, _ = ops.select_tokens(ent, am, attention_maps.shape[-1], max(top_k, 2), 2)
+    return cand[:top_k]
+
+
+def init_random_noise(device, num_words=77, dim=768):
+    """ptp_utils.py:649-650 (`dim` = the UNet's cross_attention_dim: 768 SD-1.x, 1024 SD-2.x, 2048 SDXL)."""
+    return torch.randn(1, num_words, dim).to(device)

@@ -22,8 +22,8 @@ def enable() -> bool:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
         tunable.enable(True)
         tunable.tuning_enable(os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") == "1")
-        import tempfile
-        tunable.set_filename(os.path.join(tempfile.gettempdir(), f"skp_tunableop_unused_{os.getpid()}.csv"))   # exit-time dump: never into the repo, one file per process
+        if os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") != "1":
+            tunable.write_file_on_exit(False)           # read-only use: no exit-time dump anywhere
         if os.path.exists(path):
             tunable.read_file(path)
         _done = True

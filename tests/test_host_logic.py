@@ -22,7 +22,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert name in N.SIGNATURES, f"{name} has no ctypes signature"
     assert lib.skp_abi_version() == N.ABI_VERSION
     # argument validation happens before any launch
-    assert lib.skp_token_stats_f32(None, 0, 0, 1, 1.0, 1e-5, None, None, None) == -1
+    assert lib.skp_token_stats_f32(None, 0, 0, 1, 1.0, 1e-5, None, None, None, None) == -1
 
 
 def test_product_never_imports_oracle_and_has_no_cpu_fallback():
@@ -180,7 +180,7 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert lib.skp_self_attn_fwd_f32(p, p, p, p, p, 1, 8, 64, 24, 0.1, null) == -2
     assert lib.skp_group_norm_fwd_f32(p, null, p, p, p, p, p, p, 1, 30, 32, 16, 1e-5, 1, null) == -2   # C % G
     assert lib.skp_select_tokens(p, p, 77, 128, 25, 1, p, p, null) == -2                  # top_k < 2
-    assert lib.skp_token_stats_f32(p, 77, 128, 9, 2.0, 1e-5, p, null, null) == -2          # too many subjects
+    assert lib.skp_token_stats_f32(p, 77, 128, 9, 2.0, 1e-5, p, null, null, null) == -2         # too many subjects
     assert lib.skp_losses_fwd_f32(p, p, p, 10, 77, 128, p, 1, 2.0, None, p, p, p, p, null) == -1
 
 

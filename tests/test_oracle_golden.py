@@ -94,6 +94,58 @@ def test_g3_selection(golden):
         assert torch.equal(fps, t(g[f"fps_ns{ns}"]))
 
 
+def sharp_entropy_maps(maps):
+    """The second map family of G3b (oracle/gen_golden.py): entropies spread far apart."""
+    n = maps.shape[0]
+    return torch.softmax((maps * 40.0).view(n, -1) * torch.linspace(0.2, 3.0, n)[:, None], dim=-1).view_as(maps).contiguous()
+
+
+def test_g3b_entropy_strategy(golden):
+    """top_k_strategy == 'entropy' (ptp_utils.py:165-187, optimize.py:382-385)."""
+    g = golden("g3b_entropy.npz")
+    s = SEL_CASE
+    maps, maps_t = selection_maps()
+    torch.testing.assert_close(R.token_entropy(maps), t(g["entropy"]), rtol=1e-6, atol=1e-6)
+    sm = sharp_entropy_maps(maps)
+    torch.testing.assert_close(R.token_entropy(sm), t(g["entropy_sharp"]), rtol=1e-6, atol=1e-6)
+    assert torch.equal(R.entropy_sort(sm, s["n_cand"]), t(g["entropy_sort_sharp"]))
+    top = R.entropy_sort(maps, s["n_cand"])
+    assert torch.equal(top, t(g["entropy_sort"]))
+    assert torch.equal(R.furthest_point_sampling(maps_t, s["top_k"], top), t(g["fps_entropy"]))
+
+
+def test_g9_weighted_average_keypoints(golden):
+    """eval.pixel_from_weighted_avg (eval.py:113-155) on the reference's own augmented-inference maps."""
+    g = golden("g9_reference_augmented_tiny.npz")
+    maps = t(g["maps"])
+    size = float(maps.shape[-1])
+    torch.testing.assert_close(R.pixel_from_weighted_avg(maps.clone()) / size, t(g["keypoints_weighted"]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(R.pixel_from_weighted_avg(maps.clone(), distance=3), t(g["weighted_d3"]), rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(R.pixel_from_weighted_avg(maps.clone(), distance=-1), t(g["weighted_all"]), rtol=1e-6, atol=1e-5)
+    m = maps.clone()
+    R.pixel_from_weighted_avg(m)
+    assert (m == 0).sum() > (maps == 0).sum()                 # in-place zeroing, like the reference
+
+
+def test_g10_full_size_launch_shape(golden):
+    """BASELINE config 2's real shape (SD-1.5 hooked layers, R = 128, T = 77): oracle vs the reference's checksums."""
+    from oracle.fixtures import FULL_CASE as fc
+    g = golden("g10_full_size.npz")
+    ctx = seeded((1, fc["T"], fc["ctx_dim"]), fc["seed"] + 200)
+    store = R.OracleStore()
+    with torch.no_grad():
+        for i, (sl, Cl) in enumerate(fc["layers"]):
+            w = attention_weights(Cl, fc["ctx_dim"], fc["seed"] + i)
+            R.hooked_attention(seeded((1, sl * sl, Cl), fc["seed"] + 100 + i), ctx, *w, fc["heads"], store, fc["R"])
+        m = R.collect_maps(store, upsample_res=-1)
+    flat = m.reshape(fc["T"], -1)
+    assert torch.equal(flat.argmax(dim=-1), t(g["argmax"]))
+    torch.testing.assert_close(flat.double().sum(dim=-1), t(g["token_sum"]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(m.reshape(-1)[:: fc["stride"]], t(g["strided"]), rtol=1e-4, atol=1e-7)
+    assert abs(m.double().sum().item() - float(g["checksum"])) < 1e-3          # == R*R = 16384 up to rounding
+    assert abs(float(g["checksum"]) - fc["R"] ** 2) < 1e-2
+
+
 def test_g4_losses(golden):
     g = golden("g4_losses.npz")
     s = SEL_CASE
