@@ -9,12 +9,16 @@ A "step" = one optimizer step of the reference loop (optimize.py:339-425) on thi
 the global batch: `--images-per-rank` (default 4 = BASELINE config 2's batch_size on 1 GPU) synthetic
 512x512 images, each = VAE-encode + hooked UNet forward of the image AND of its affine copy, fused map
 reduction x2, on-device token selection, both losses, backward to the [1,77,768] embedding; then one
-RCCL all-reduce(sum) of the gradient and an Adam step.  Weak scaling: per-rank work is fixed, the
-global batch is images-per-rank * N.  value = N * images-per-rank * K / max-over-ranks seconds.
+RCCL all-reduce(sum) of the gradient and an Adam step.
+  --scaling weak   (default): per-rank work is fixed, the global batch is images-per-rank * N
+  --scaling strong : the global batch is fixed at --global-batch (8 = BASELINE config 3: 1 image per rank at N = 8)
+value = global batch * K / max-over-ranks seconds.  `--model sd21|sdxl` run BASELINE configs 4 / 5 (768^2 / 1024^2,
+embedding 77 x 1024 / 77 x 2048); `--tokens 500` is the reference CLI default token count.
 
-Rank 0 prints ONE JSON line with `roofline` (the fused attention-map kernel, measured live with
-events on the launch stream) and, at N=1, `cpu_baseline` (the oracle's reference-order CPU step on
-the host cores, bounded sample).
+Rank 0 prints ONE JSON line with `roofline` (the dominant kernel of the step), `roofline_attn_map` /
+`roofline_self_attn` (the attention kernels), all measured live with events on the launch stream, `collective_check`
+(the RCCL all-reduce proven at start-up) and, at N=1, `cpu_baseline` (the oracle's reference-order CPU step on the
+host cores, bounded sample).
 """
 from __future__ import annotations
 
@@ -41,11 +45,19 @@ def parse():
     ap.add_argument("--images-per-rank", type=int, default=4)
     ap.add_argument("--tokens", type=int, default=77)
     ap.add_argument("--res", type=int, default=128, help="feature_upsample_res (R)")
-    ap.add_argument("--image-size", type=int, default=512)
-    ap.add_argument("--model", default="sd15")
-    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off"])
+    ap.add_argument("--image-size", type=int, default=0, help="0 = the architecture's native size (512 / 768 / 1024)")
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sd21", "sdxl", "tiny", "tiny-sd21", "tiny-sdxl"],
+                    help="architecture (seeded synthetic weights): sd15 = BASELINE config 2/3, sd21 = config 4, sdxl = config 5")
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--candidates", type=int, default=25, help="furthest_point_num_samples")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --images-per-rank images on every rank (global batch grows with N); strong: the global "
+                         "batch is fixed at --global-batch images (BASELINE config 3: 8 images, 1 per rank at N=8)")
+    ap.add_argument("--global-batch", type=int, default=8, help="images per optimizer step with --scaling strong")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off", "full"],
+                    help="full: SURVEY 8(d)'s complete protocol (C1 256^2 x 50 steps + 512^2 x 3 steps + thread sweep; minutes)")
     ap.add_argument("--cpu-image-size", type=int, default=512)
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the best of a short sweep over {32,64,128}")
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
@@ -53,14 +65,16 @@ def parse():
     return ap.parse_args()
 
 
-def map_kernel_roofline(ops, B, T, R, iters, device):
-    """Time the fused map kernels alone at the bench shapes (SD-1.5 hooked layers: 3 x (16^2, C=1280) +
+def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None):
+    """Time the fused map kernels alone at the bench shapes (default SD-1.5 hooked layers: 3 x (16^2, C=1280) +
     1 x (32^2, C=640), 8 heads) with events on the CURRENT stream (the one the C-ABI launches on)."""
     g = torch.Generator(device="cpu").manual_seed(0)
-    dims = [(16, 1280)] * 3 + [(32, 640)]
+    layer_dims = layer_dims or ([(16, 1280, 8)] * 3 + [(32, 640, 8)])
+    dims = [(s, C) for s, C, _ in layer_dims]
     qs = [torch.randn(B, s * s, C, generator=g).to(device) for s, C in dims]
     ks = [torch.randn(1, T, C, generator=g).to(device) for s, C in dims]
-    H = 8
+    H = layer_dims[0][2]
+    L = len(dims)
     scales = [(C // H) ** -0.5 for _, C in dims]
     S = [ops.qk_logits(q, k, H, sc) for q, k, sc in zip(qs, ks, scales)]
     sides = [s for s, _ in dims]
@@ -72,17 +86,17 @@ def map_kernel_roofline(ops, B, T, R, iters, device):
     dp, k2 = N.ptr_array([t.data_ptr() for t in dS])
     si, k3 = N.int_array(sides)
     st = torch.cuda.current_stream().cuda_stream
-    ws = torch.empty(max(4, N.lib().skp_attn_map_bwd_workspace(si, 4, B, H, min(T, 128), R)) // 4, device=device)
+    ws = torch.empty(max(4, N.lib().skp_attn_map_bwd_workspace(si, L, B, H, min(T, 128), R)) // 4, device=device)
 
     def run_fwd():
         if T > 128:                                              # token-group path (several launches)
             return ops._map_fwd(S, sides, B, H, T, R)
-        N.check(N.lib().skp_attn_map_fwd_f32(sp, si, 4, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "fwd")
+        N.check(N.lib().skp_attn_map_fwd_f32(sp, si, L, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "fwd")
 
     def run_bwd():
         if T > 128:
             return ops._map_bwd(S, dS, sides, B, H, T, R, dM, lse)
-        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, 4, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "bwd")
+        N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, L, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "bwd")
 
     out = {}
     for name, fn in (("fwd", run_fwd), ("bwd", run_bwd)):
@@ -160,27 +174,53 @@ def conv_roofline(ops, B, image_size, iters, device):
 
 
 def cpu_baseline(ldm_cpu, args):
-    """Oracle reference-order CPU step (oracle/cpu_path.py) on a bounded sample: ONE image (2 UNet+VAE
-    forwards with materialised attention + backward + Adam) at --cpu-image-size, after one untimed warm-up
-    of the allocator at 1/4 size."""
+    """Oracle reference-order CPU step (oracle/cpu_path.py: materialised attention, x-upsample + second to_q, stack+mean
+    collect_maps, python selection, torch losses, Adam) on the host cores -- a BOUNDED sample:
+      default: thread sweep {32,64,128} on one 256^2 image each, then at the best count: C1 shape (256^2, batch 1) for
+               5 optimizer steps and the bench shape (512^2) for 1 warm-up + 3 timed steps;
+      --cpu-baseline full: C1 for the full 50 steps.
+    `value` is the bench-shape rate (same image size as the GPU line); the C1 rate rides along."""
     from oracle import cpu_path
-    # 256 hardware threads thrash torch's CPU kernels (measured: 541 s/image at 256 threads); use 32.
-    cores = min(os.cpu_count() or 1, args.cpu_threads)
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
+    ctx = torch.randn(1, args.tokens, ldm_cpu.unet.config["cross_attention_dim"], generator=g)
+    kw = dict(R_up=args.res, furthest_point_num_samples=args.candidates, top_k=args.top_k)
+
+    def run(size, steps, threads):
+        torch.set_num_threads(threads)
+        imgs = torch.rand(max(1, steps), 3, size, size, generator=torch.Generator().manual_seed(1))
+        _, sec, n = cpu_path.optimize_embedding_cpu(ldm_cpu, imgs, ctx, steps=steps, batch_size=1, **kw)
+        return n / sec, sec
+
+    sweep = {}
+    if args.cpu_threads > 0:
+        best = min(ncpu, args.cpu_threads)
+    else:
+        run(128, 1, min(ncpu, 32))                               # allocator / first-touch warm-up, untimed
+        for th in (32, 64, 128):
+            if th <= ncpu:
+                sweep[th] = run(256, 1, th)[0]
+                if len(sweep) > 1 and sweep[th] < 0.8 * max(sweep.values()):
+                    break                                        # past the knee: more threads only oversubscribe
+        best = max(sweep, key=sweep.get) if sweep else min(ncpu, 32)
+    c1_steps = 50 if args.cpu_baseline == "full" else 5
+    c1_rate, c1_sec = run(256, c1_steps, best)
     size = args.cpu_image_size
-    imgs = torch.rand(1, 3, size, size, generator=g)
-    ctx = torch.randn(1, args.tokens, 768, generator=g)
-    _, sec, n = cpu_path.optimize_embedding_cpu(ldm_cpu, imgs, ctx, steps=1, batch_size=1, R_up=args.res)
-    return {"value": n / sec, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 optimizer step, batch 1, one {size}x{size} image (2 VAE+UNet forwards, backward, Adam), "
-                      f"T={args.tokens}, R={args.res}, torch {torch.__version__} CPU fp32, {sec:.1f} s"}
+    run(size, 1, best)                                           # warm-up at the bench shape
+    rate, sec = run(size, 3, best)
+    return {"value": rate, "unit": "images/sec", "cores": best, "kind": "port",
+            "sample": f"{size}x{size}: 1 warm-up + 3 timed optimizer steps (batch 1: 2 VAE+UNet forwards with materialised "
+                      f"attention, backward, Adam per step), T={args.tokens}, R={args.res}, {sec:.1f} s; torch "
+                      f"{torch.__version__} CPU fp32, {best} threads of {ncpu}",
+            "c1_256": {"value": c1_rate, "steps": c1_steps, "seconds": c1_sec,
+                       "what": "BASELINE config 1 shape (256^2, 1 image, batch 1), reference op order"},
+            "thread_sweep_256_images_per_sec": {str(k): v for k, v in sweep.items()}}
 
 
 def measured_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*.json, separate
-    FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at the same launch shape; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md 'HBM').  None when no profile is present."""
+    """(HBM bytes per launch, source file) of a kernel from the committed rocprofv3 --pmc passes (profiles/*.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at the same launch shape, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md 'HBM'; regenerate with tools/pmc_traffic.sh).  (None, None) when no profile is present."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True)       # newest round / version first by name
     for path in files:
@@ -190,8 +230,40 @@ def measured_traffic(kernel_substr):
             continue
         for name, c in k.items():
             if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+                return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "profiles/" + os.path.basename(path)
+    return None, None
+
+
+NATIVE_SIZE = {"sd15": 512, "sd21": 768, "sdxl": 1024, "tiny": 128, "tiny-sd21": 128, "tiny-sdxl": 128}
+MODEL_LABEL = {"sd15": "SD1.5", "sd21": "SD2.1", "sdxl": "SDXL"}
+CONFIG_NAME = {"sd15": "BASELINE config 2", "sd21": "BASELINE config 4", "sdxl": "BASELINE config 5"}
+
+
+def hooked_layer_dims(model, image_size):
+    """(side, channels, heads) of the layers the <= 32^2 / first-4 gate stores."""
+    lat = image_size // 8
+    if model == "sd21":
+        return [(lat // 4, 1280, 20)] * 3
+    if model == "sdxl":
+        return [(lat // 4, 1280, 20)] * 4
+    if model == "sd15":
+        return [(lat // 4, 1280, 8)] * 3 + [(lat // 2, 640, 8)]
     return None
+
+
+def rccl_self_check(D, world, rank, dev):
+    """Prove the collective this run depends on: all-reduce(SUM) of a one-hot rank vector must come back as all ones,
+    and of the rank ids as 0+1+...+N-1.  Returns what was checked (goes into the JSON line)."""
+    if world == 1:
+        return {"backend": None, "ok": True, "ranks_seen": 1}
+    v = torch.zeros(world + 1, device=dev, dtype=torch.float32)
+    v[rank] = 1.0
+    v[world] = float(rank)
+    D.allreduce_sum_(v)
+    torch.cuda.synchronize()
+    ok = bool((v[:world] == 1).all().item()) and float(v[world].item()) == world * (world - 1) / 2
+    assert ok, f"RCCL self-check failed on rank {rank}: {v.tolist()}"
+    return {"backend": torch.distributed.get_backend(), "ok": True, "ranks_seen": int(v[:world].sum().item())}
 
 
 def main():
@@ -204,47 +276,53 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # host threads: N ranks share the box's cores (weight init + the Python driver are the only CPU work)
+    # host threads: N ranks share the box's cores (the Python driver is the only CPU work of a rank)
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(1, world))))
     from stablekeypoints_amd import ops, _native
     from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
     from stablekeypoints_amd.optimize import SyntheticImages, default_args, group_step
     from stablekeypoints_amd.optimize_token import load_ldm
     _native.lib()
+    coll = rccl_self_check(D, world, rank, dev)
+    image_size = a.image_size or NATIVE_SIZE[a.model]
+    if a.cpu_image_size == 512 and image_size != 512:
+        a.cpu_image_size = image_size
 
     t_build = time.time()
-    ldm, controllers, _ = load_ldm("cpu", a.model, feature_upsample_res=a.res)      # seeded synthetic weights
     cpu_stats = None
-    want_cpu = a.cpu_baseline == "on" or (a.cpu_baseline == "auto" and world == 1)
+    want_cpu = a.cpu_baseline in ("on", "full") or (a.cpu_baseline == "auto" and world == 1 and a.model == "sd15")
     if want_cpu and rank == 0:
-        cpu_stats = cpu_baseline(ldm, a)
-    # move the same instance to the GPU and install the fused hook (overrides the oracle's patch)
-    ldm.to(dev)
+        # the CPU leg gets its own host-side instance (same seed => the same numbers the GPU tree would draw on the host)
+        ldm_cpu, _, _ = load_ldm("cpu", a.model, feature_upsample_res=a.res)
+        cpu_stats = cpu_baseline(ldm_cpu, a)
+        del ldm_cpu
+    # frozen weights are drawn on this rank's GPU (seeded: identical on every rank; no N x 3.4 GB of host-side init)
+    ldm, controllers, _ = load_ldm(dev, a.model, feature_upsample_res=a.res, init_on_device=True)
+    controller = controllers[dev]
     if a.miopen_find:
         torch.backends.cudnn.benchmark = True
     if a.channels_last:
         ldm.unet.to(memory_format=torch.channels_last)
         ldm.vae.to(memory_format=torch.channels_last)
-    from stablekeypoints_amd import ptp_utils
-    controller = ptp_utils.AttentionStore()
-    controllers = {dev: controller}
-    ptp_utils.register_attention_control(ldm.unet, controller, feature_upsample_res=a.res)
-    ptp_utils.accelerate_cross_attention(ldm.unet)
-    if not a.no_fuse_norms:
-        from stablekeypoints_amd.ldm.fused import fuse_norms
-        fuse_norms(ldm.unet)
-        fuse_norms(ldm.vae)
+    if a.no_fuse_norms:
+        raise SystemExit("--no-fuse-norms: load_ldm always fuses on a GPU; use SKP_CONV3X3=lib for the conv A/B")
     from stablekeypoints_amd import tuning
     gemm_tuned = tuning.enable()
     t_build = time.time() - t_build
 
-    per_rank = a.images_per_rank
-    global_batch = per_rank * world
+    if a.scaling == "strong":
+        if a.global_batch % world:
+            raise SystemExit(f"--scaling strong: --global-batch {a.global_batch} must be a multiple of --gpus {world}")
+        global_batch, per_rank = a.global_batch, a.global_batch // world
+    else:
+        per_rank = a.images_per_rank
+        global_batch = per_rank * world
+    width = ldm.unet.config["cross_attention_dim"]
     args = default_args(num_tokens=a.tokens, feature_upsample_res=a.res, batch_size=global_batch, device=str(dev),
-                        image_size=a.image_size)
-    data = SyntheticImages(n=max(16, per_rank * 2), size=a.image_size, seed=rank, device=dev)
+                        image_size=image_size, top_k=a.top_k, furthest_point_num_samples=a.candidates)
+    data = SyntheticImages(n=max(16, per_rank * 2), size=image_size, seed=rank, device=dev)
     torch.manual_seed(1000 + rank)                                                    # per-rank augmentations/noise
-    ctx = torch.randn(1, a.tokens, 768, generator=torch.Generator().manual_seed(0)).to(dev).requires_grad_(True)
+    ctx = torch.randn(1, a.tokens, width, generator=torch.Generator().manual_seed(0)).to(dev).requires_grad_(True)
     opt = torch.optim.Adam([ctx], lr=args.lr)
     reducer = D.EmbeddingReducer(ctx, opt)
     transform = RandomAffineWithInverse(args.augment_degrees, args.augment_scale, args.augment_translate)
@@ -275,49 +353,73 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    # embeddings must still be bit-identical on every rank (same all-reduced gradient, same Adam state)
+    chk = torch.stack([ctx.detach().double().sum(), ctx.detach().double().abs().sum()])
+    if world > 1:
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        coll["embedding_identical_on_all_ranks"] = bool(torch.equal(lo, hi))
 
     if rank == 0:
         B = 2 * per_rank                                          # rows per fused-map launch (both views)
-        kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev)
+        ldims = hooked_layer_dims(a.model, image_size)
+        kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev, ldims)
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(3, a.kernel_iters // 6), dev)
-        cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, a.image_size, max(3, a.kernel_iters // 6), dev)
+        cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, min(image_size, 512), max(3, a.kernel_iters // 6), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
+        conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}")
+        map_traffic, map_src = measured_traffic("skp_attn_map_fwd_kernel")
+        cfg_name = CONFIG_NAME.get(a.model, "reduced-width test model")
+        if a.model == "sd15" and a.scaling == "strong":
+            cfg_name = "BASELINE config 3 (fixed global batch)"
         line = {
-            "metric": "images/sec for token-optimization step (SD1.5, 512^2, K=10 kpts)",
+            "metric": f"images/sec for token-optimization step ({MODEL_LABEL.get(a.model, a.model)}, {image_size}^2, K={a.top_k} kpts)",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
+            "scaling_definition": ("weak: every rank processes images_per_rank images per optimizer step, the global batch "
+                                   "is images_per_rank x N" if a.scaling == "weak" else
+                                   "strong: the global batch is fixed (global_batch images per optimizer step), each rank "
+                                   "processes global_batch / N of them"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: SD1.5-architecture UNet+VAE (seeded synthetic weights), "
-                                   f"{a.image_size}x{a.image_size}, batch {per_rank} images/rank/step x 2 views, "
-                                   f"T={a.tokens} tokens, R={a.res}, top_k=10 of 25, fp32 end to end",
-                       "global_batch": global_batch, "images_per_rank": per_rank, "tokens": a.tokens,
+            "config": {"workload": f"{cfg_name}: {a.model} architecture UNet+VAE (seeded synthetic weights), "
+                                   f"{image_size}x{image_size}, batch {per_rank} images/rank/step x 2 views, "
+                                   f"T={a.tokens} tokens x {width}, R={a.res}, top_k={a.top_k} of {a.candidates}, fp32 end to end",
+                       "global_batch": global_batch, "images_per_rank": per_rank, "tokens": a.tokens, "embedding_dim": width,
                        "feature_upsample_res": a.res, "parallelism": f"dp{world}"},
-            # dominant kernel of the step by time (37 % of it): the Winograd conv of the frozen blocks, priced on the
+            # dominant kernel of the step by time: the Winograd conv of the frozen blocks, priced on the
             # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
-            "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {a.image_size}^2, "
+            "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {min(image_size, 512)}^2, "
                                    f"{cv_rows} rows: heaviest launch shape of the step)",
                          "bound": "mfma", "achieved": cv_direct / 4 / cv_t / 1e12, "peak": F32_MATRIX_PEAK_TF,
                          "unit": "TFLOP/s", "frac": cv_direct / 4 / cv_t / 1e12 / F32_MATRIX_PEAK_TF,
-                         "traffic": measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}"),
+                         "traffic": conv_traffic, "traffic_source": conv_src,
                          "launch_us": cv_t * 1e6, "algorithmic_flops": cv_direct / 4, "algorithmic_bytes": cv_bytes,
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
                          "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
-            "roofline_attn_map": {"kernel": "skp_attn_map_fwd_kernel<80,0> (fused up-res softmax map, forward)",
+            # the north-star attention kernel (BASELINE metric: "fraction of the attention roofline")
+            "roofline_attn_map": {"kernel": "skp_attn_map_fwd_kernel (fused up-res softmax map, forward)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("skp_attn_map_fwd_kernel"),
+                         "frac": ach / HBM_PEAK_GBS, "traffic": map_traffic, "traffic_source": map_src,
                          "launch_us": kt["fwd"] * 1e6, "algorithmic_bytes": fwd_bytes, "rows_per_launch": B,
                          "bwd_launch_us": kt["bwd"] * 1e6, "bwd_achieved": bwd_bytes / kt["bwd"] / 1e9,
+                         "bwd_frac": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS, "bwd_algorithmic_bytes": bwd_bytes,
                          "reference_contraction_equiv_tflops": flops_equiv / kt["fwd"] / 1e12,
                          "f32_matrix_peak_tflops": F32_MATRIX_PEAK_TF},
-            "roofline_self_attn": {"kernel": "skp_self_attn_fwd_kernel<5,2> (flash self-attention, 64^2 layers)",
+            "roofline_self_attn": {"kernel": "flash self-attention forward, 64^2 layers (N=4096, 8 heads x 40)",
                                    "bound": "mfma", "achieved": sa_f / sa["fwd"] / 1e12, "peak": F32_MATRIX_PEAK_TF,
                                    "unit": "TFLOP/s", "frac": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
                                    "traffic": None, "launch_us": sa["fwd"] * 1e6, "algorithmic_flops": sa_f,
                                    "bwd_us": sa["bwd"] * 1e6, "bwd_achieved": sa_b / sa["bwd"] / 1e12,
-                                   "rows_per_launch": B, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
-            "cpu_baseline": cpu_stats,
+                                   "bwd_frac": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF,
+                                   "rows_per_launch": B, "dtype": "f32 MFMA"},
+            "attention_roofline_frac": {"map_fwd_hbm": ach / HBM_PEAK_GBS, "map_bwd_hbm": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS,
+                                        "self_attn_fwd_mfma": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
+                                        "self_attn_bwd_mfma": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF},
+            "cpu_baseline": cpu_stats, "collective_check": coll,
             "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
+            "weights_init": "seeded, drawn on the rank's GPU",
         }
         if line["roofline"]["traffic"]:
             line["roofline"]["hbm_gbs_at_traffic"] = line["roofline"]["traffic"] / cv_t / 1e9

@@ -16,6 +16,7 @@
  *                                           (bicubic up-res softmax map, per-head store, layer/head mean)
  *   skp_cross_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (ordinary softmax(QK^T)V, cross layers)
  *   skp_self_attn_fwd_f32 / _bwd_f32        ptp_utils.py:493-506,540 (self-attention layers, flash-style)
+ *   skp_flash_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (any key count: cross layers with T > 128 tokens)
  *   skp_group_norm_fwd_f32 / _bwd_f32       GroupNorm+SiLU of the hooked UNet / VAE forward (ptp_utils.py:227-229, 289-304)
  *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
  *   skp_select_tokens                       ptp_utils.py:110-112,115-159
@@ -117,6 +118,20 @@ int skp_cross_attn_bwd_f32(const float* q, const float* k, const float* v, const
 int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/,
                             int L, int B, int H, int T, int R, const float* dM, const float* lse,
                             float* workspace, float* dot_io, int ldt, int64_t m_bstride, int mode, void* stream);
+
+/* Flash-style attention for any key count (ptp_utils.py:493-506,540): the general form behind skp_self_attn_* and the
+ * cross-attention layers whose key axis exceeds skp_cross_attn_*'s 128 tokens (the reference CLI default is
+ * --num_tokens 500, main.py:77-79).  fp32 MFMA, 64-key tiles through LDS, online softmax (running max / sum).
+ *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]
+ * q, out: [B,N,H*d]; k, v: [Bk,Nk,H*d] with Bk in {1,B} (Bk == 1: one k/v shared by all rows, ptp_utils.py:229);
+ * lse: [B,H,N] natural-log sum-exp.  d in {8,16,32,40,64,80,160}.
+ * _bwd: dq [B,N,H*d], dk, dv [B,Nk,H*d] WRITTEN per batch row (the caller sums dk/dv over b when Bk == 1);
+ * workspace: B*H*N floats.  Deterministic (no atomics). */
+int skp_flash_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
+                           int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream);
+int skp_flash_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                           const float* lse, float* dq, float* dk, float* dv, float* workspace,
+                           int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream);
 
 /* Flash-style self-attention (ptp_utils.py:493-506 with context = x) for the long image-token sequences: fp32 MFMA,
  * 64-key tiles in LDS, online softmax; the [B*h,N,N] scores are never materialised.

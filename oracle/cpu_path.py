@@ -16,8 +16,10 @@ import torch
 from . import ref_path as R
 
 
-def register_reference_hook(unet, store: R.OracleStore, feature_upsample_res: int) -> int:
-    """ptp_utils.py:555-573 restated: patch class-named `CrossAttention` modules under '*up*' children."""
+def register_reference_hook(unet, store: R.OracleStore, feature_upsample_res: int, max_seq: int = 32 ** 2) -> int:
+    """ptp_utils.py:555-573 restated: patch class-named `CrossAttention` modules under '*up*' children.
+    `max_seq` is the reference's hard-coded 32**2 gate (ptp_utils.py:510); tests shrink it to reproduce, on a small
+    latent grid, the SD-2.x @768^2 situation where only three layers pass the gate."""
     count = 0
 
     def patch(mod):
@@ -25,7 +27,8 @@ def register_reference_hook(unet, store: R.OracleStore, feature_upsample_res: in
 
         def forward(x, context=None, mask=None):
             return R.hooked_attention(x, context, mod.to_q.weight, mod.to_k.weight, mod.to_v.weight,
-                                      to_out.weight, to_out.bias, mod.heads, store, feature_upsample_res)
+                                      to_out.weight, to_out.bias, mod.heads, store, feature_upsample_res,
+                                      max_seq=max_seq)
         mod.forward = forward
 
     def rec(net):

@@ -85,3 +85,9 @@ def selection_maps():
     maps[5, 10, 20] = 1.5          # equal maxima: argmax must report (3,4)
     maps_t[6, 31, 31] = 1.25
     return maps, maps_t
+
+
+def sharp_entropy_maps(maps):
+    """The second map family of G3b (oracle/gen_golden.py): per-token entropies spread far apart."""
+    n = maps.shape[0]
+    return torch.softmax((maps * 40.0).view(n, -1) * torch.linspace(0.2, 3.0, n)[:, None], dim=-1).view_as(maps).contiguous()

@@ -170,8 +170,8 @@ def main():
     g3b["entropy"] = torch.distributions.Categorical(probs=sm).entropy().numpy()
     g3b["fps_entropy"] = ptp_utils.furthest_point_sampling(maps_t, s["top_k"], ent_top).numpy()
     # a sharper family of maps (entropies far apart) so the ranking is not decided by rounding
-    sharp_maps = torch.softmax((maps * 40.0).view(maps.shape[0], -1) * torch.linspace(0.2, 3.0, maps.shape[0])[:, None],
-                               dim=-1).view_as(maps).contiguous()
+    from oracle.fixtures import sharp_entropy_maps
+    sharp_maps = sharp_entropy_maps(maps)
     g3b["entropy_sort_sharp"] = ptp_utils.entropy_sort(sharp_maps, s["n_cand"]).numpy()
     g3b["entropy_sharp"] = torch.distributions.Categorical(
         probs=torch.softmax(sharp_maps.view(maps.shape[0], -1), dim=-1)).entropy().numpy()

@@ -55,7 +55,7 @@ def merge_heads(t: torch.Tensor, heads: int) -> torch.Tensor:
 
 
 def hooked_attention(x, context, wq, wk, wv, wo, bo, heads, store: Optional[OracleStore],
-                     feature_upsample_res: int, max_stored: int = 4):
+                     feature_upsample_res: int, max_stored: int = 4, max_seq: int = 32 ** 2):
     """ptp_utils.py:480-541.  Weights are nn.Linear-style (out,in); to_q/k/v have no bias.
 
     Returns the layer output; appends the up-res probability tensor (B*h, R*R, T) to `store`
@@ -73,7 +73,7 @@ def hooked_attention(x, context, wq, wk, wv, wo, bo, heads, store: Optional[Orac
     sim = torch.einsum("bid,bjd->bij", q, k) * scale            # :493
     attn = sim.softmax(dim=-1).clone()                          # :503-504
     out = torch.matmul(attn, v)                                 # :506
-    if (is_cross and seq <= 32 ** 2 and store is not None
+    if (is_cross and seq <= max_seq and store is not None
             and len(store.step_store["attn"]) < max_stored):   # :508-512
         side = int(seq ** 0.5)
         xr = x.reshape(bsz, side, side, dim).permute(0, 3, 1, 2)            # :513-518

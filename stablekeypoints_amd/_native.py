@@ -50,6 +50,8 @@ SIGNATURES = {
     "skp_geglu_bwd_f32": [_vp, _vp, _vp, _i64, _i, _vp],
     "skp_nchw_to_tokens_f32": [_vp, _vp, _i, _i, _i, _vp],
     "skp_tokens_to_nchw_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "skp_flash_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_flash_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "skp_self_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "skp_self_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
 }

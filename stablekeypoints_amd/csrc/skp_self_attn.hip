@@ -13,6 +13,7 @@
 //             D[n] = rowsum(dO * O) is computed by the dQ kernel and handed to the dKV kernel through HBM.
 // Deterministic (no atomics).  Head dims 8/16/40/80/160 (d = 160 backward uses a 32-key tile to fit registers).
 #include "skp_attn_tiles.h"
+#include <stdlib.h>
 
 // store a transposed accumulator (rows = channels, lane = query/key row) as out[row, c] * mul
 template <int D8, int TT>
@@ -33,7 +34,10 @@ __device__ __forceinline__ void sa_store_t(const f32x16 (&o)[CAShape<D8, TT>::CT
 template <int D8, int KT32>
 __global__ __launch_bounds__(256) void skp_self_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                 const float* __restrict__ v, float* __restrict__ out,
-                                                                float* __restrict__ lse, int H, int N, float scale) {
+                                                                float* __restrict__ lse, int H, int N, int Nk, int kvb,
+                                                                float scale) {
+    // N queries, Nk keys; kvb = 1: k/v have a batch axis, 0: one k/v shared by every batch row (cross-attention with
+    // the learned embedding, ptp_utils.py:229)
     using S = CAShape<D8, KT32>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void skp_self_attn_fwd_kernel(const float* __r
     const int n = blockIdx.x * 128 + wave * 32 + i;
     const bool nv = n < N;
     const size_t rowoff = ((size_t)b * N + (nv ? n : N - 1)) * C + h * S::D;
-    const size_t hoff = (size_t)b * N * C + (size_t)h * S::D;
+    const size_t hoff = (size_t)(kvb ? b : 0) * Nk * C + (size_t)h * S::D;
     f32x4 qv[D8];
 #pragma unroll
     for (int j = 0; j < D8; ++j) qv[j] = *(const f32x4*)(q + rowoff + 8 * j + 4 * hi) * (scale * SKP_LOG2E);
@@ -53,10 +57,10 @@ __global__ __launch_bounds__(256) void skp_self_attn_fwd_kernel(const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
     float m = -INFINITY, l = 0.f;
-    for (int kt0 = 0; kt0 < N; kt0 += S::TP) {
+    for (int kt0 = 0; kt0 < Nk; kt0 += S::TP) {
         __syncthreads();                                       // previous tile consumed
-        ca_stage<D8, KT32>(Ks, k + hoff + (size_t)kt0 * C, N - kt0, C, tid);
-        ca_stage<D8, KT32>(Vs, v + hoff + (size_t)kt0 * C, N - kt0, C, tid);
+        ca_stage<D8, KT32>(Ks, k + hoff + (size_t)kt0 * C, Nk - kt0, C, tid);
+        ca_stage<D8, KT32>(Vs, v + hoff + (size_t)kt0 * C, Nk - kt0, C, tid);
         __syncthreads();
         f32x16 acc[KT32];
 #pragma unroll
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void skp_self_attn_fwd_kernel(const float* __r
             for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
         ca_swapped_product<D8, KT32>(Ks, qv, acc, i, hi);
         float tm = -INFINITY;
-        const int left = N - kt0;
+        const int left = Nk - kt0;
 #pragma unroll
         for (int tt = 0; tt < KT32; ++tt)
 #pragma unroll
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dq_kernel(const float* 
                                                                    const float* __restrict__ v, const float* __restrict__ out,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
                                                                    float* __restrict__ dq, float* __restrict__ Dbuf, int H,
-                                                                   int N, float scale) {
+                                                                   int N, int Nk, int kvb, float scale) {
     using S = CAShape<D8, KT32>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dq_kernel(const float* 
     const int n = blockIdx.x * 128 + wave * 32 + i;
     const bool nv = n < N;
     const size_t rowoff = ((size_t)b * N + (nv ? n : N - 1)) * C + h * S::D;
-    const size_t hoff = (size_t)b * N * C + (size_t)h * S::D;
+    const size_t hoff = (size_t)(kvb ? b : 0) * Nk * C + (size_t)h * S::D;
     f32x4 qv[D8], dov[D8];
     float dsum = 0.f;
 #pragma unroll
@@ -131,10 +135,10 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dq_kernel(const float* 
     for (int ct = 0; ct < S::CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqa[ct][r] = 0.f;
-    for (int kt0 = 0; kt0 < N; kt0 += S::TP) {
+    for (int kt0 = 0; kt0 < Nk; kt0 += S::TP) {
         __syncthreads();
-        ca_stage<D8, KT32>(Ks, k + hoff + (size_t)kt0 * C, N - kt0, C, tid);
-        ca_stage<D8, KT32>(Vs, v + hoff + (size_t)kt0 * C, N - kt0, C, tid);
+        ca_stage<D8, KT32>(Ks, k + hoff + (size_t)kt0 * C, Nk - kt0, C, tid);
+        ca_stage<D8, KT32>(Vs, v + hoff + (size_t)kt0 * C, Nk - kt0, C, tid);
         __syncthreads();
         f32x16 p[KT32], dp[KT32];
 #pragma unroll
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dq_kernel(const float* 
             for (int r = 0; r < 16; ++r) { p[tt][r] = 0.f; dp[tt][r] = 0.f; }
         ca_swapped_product<D8, KT32>(Ks, qv, p, i, hi);
         ca_swapped_product<D8, KT32>(Vs, dov, dp, i, hi);
-        const int left = N - kt0;
+        const int left = Nk - kt0;
 #pragma unroll
         for (int tt = 0; tt < KT32; ++tt)
 #pragma unroll
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dkv_kernel(const float*
                                                                     const float* __restrict__ v, const float* __restrict__ dout,
                                                                     const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                     float* __restrict__ dk, float* __restrict__ dv, int H, int N,
-                                                                    float scale) {
+                                                                    int Nk, int kvb, float scale) {
+    // dk, dv are written per batch row [B,Nk,C] (the caller sums over b when kvb == 0)
     using S = CAShape<D8, QT32>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
@@ -171,15 +176,16 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dkv_kernel(const float*
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, C = H * S::D;
     const int t = blockIdx.x * 128 + wave * 32 + i;            // this lane's key
-    const bool tv = t < N;
-    const size_t rowoff = ((size_t)b * N + (tv ? t : N - 1)) * C + h * S::D;
+    const bool tv = t < Nk;
+    const size_t krow = ((size_t)(kvb ? b : 0) * Nk + (tv ? t : Nk - 1)) * C + h * S::D;
+    const size_t rowoff = ((size_t)b * Nk + (tv ? t : Nk - 1)) * C + h * S::D;      // dk/dv row (always per batch row)
     const size_t hoff = (size_t)b * N * C + (size_t)h * S::D;
     const size_t soff = ((size_t)b * H + h) * N;
     f32x4 kv[D8], vv[D8];
 #pragma unroll
     for (int j = 0; j < D8; ++j) {
-        kv[j] = *(const f32x4*)(k + rowoff + 8 * j + 4 * hi) * (scale * SKP_LOG2E);
-        vv[j] = *(const f32x4*)(v + rowoff + 8 * j + 4 * hi);
+        kv[j] = *(const f32x4*)(k + krow + 8 * j + 4 * hi) * (scale * SKP_LOG2E);
+        vv[j] = *(const f32x4*)(v + krow + 8 * j + 4 * hi);
     }
     f32x16 dka[S::CT], dva[S::CT];
 #pragma unroll
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(256) void skp_self_attn_bwd_dkv_kernel(const float*
     }
 }
 
-static int sa_check(int B, int H, int N, int d) {
-    if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return SKP_E_BADARG;
+static int sa_check(int B, int Bk, int H, int N, int Nk, int d) {
+    if (B <= 0 || H <= 0 || N <= 0 || Nk <= 0 || d <= 0 || (Bk != 1 && Bk != B)) return SKP_E_BADARG;
     if (B > 65535 || H > 65535) return SKP_E_RANGE;
     if (d != 8 && d != 16 && d != 32 && d != 40 && d != 64 && d != 80 && d != 160) return SKP_E_RANGE;
     return 0;
@@ -240,53 +246,90 @@ static int sa_check(int B, int H, int N, int d) {
         hipLaunchKernelGGL((KERNEL<D8V, T32V>), grid, block, lds, st, __VA_ARGS__);                      \
     }
 
-extern "C" int skp_self_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
-                                     int B, int H, int N, int d, float scale, void* stream) {
+// second-generation kernels (skp_flash_attn.hip); -100 = head size not built there
+int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, float* lse, int B, int Bk, int H, int N,
+                int Nk, int d, float scale, void* stream);
+int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
+                float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
+                float scale, void* stream);
+
+static bool sa_gen1() {                                         // SKP_FLASH_GEN=1 forces the first-generation kernels (A/B runs)
+    const char* e = getenv("SKP_FLASH_GEN");
+    return e && e[0] == '1';
+}
+
+extern "C" int skp_flash_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
+                                      int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream) {
     if (!q || !k || !v || !out || !lse) return SKP_E_BADARG;
-    int rc = sa_check(B, H, N, d);
+    int rc = sa_check(B, Bk, H, N, Nk, d);
     if (rc) return rc;
+    if (!sa_gen1()) {
+        rc = skp_fa2_fwd(q, k, v, out, lse, B, Bk, H, N, Nk, d, scale, stream);
+        if (rc != -100) return rc;
+    }
+    const int kvb = Bk == 1 ? 0 : 1;
     dim3 grid((N + 127) / 128, H, B), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
-        case 8: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 1, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
-        case 16: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 2, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
-        case 32: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 4, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
-        case 40: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 5, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
-        case 64: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 8, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
-        case 80: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 10, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
-        default: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 20, 2, 2, 0, q, k, v, out, lse, H, N, scale) break;
+        case 8: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 1, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        case 16: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 2, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        case 32: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 4, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        case 40: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 5, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        case 64: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 8, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        case 80: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 10, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        default: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 20, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
     }
     return skp_launch_status();
 }
 
 /* workspace: B*H*N floats (D = rowsum(dO*O)) */
-extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
-                                     const float* dout, const float* lse, float* dq, float* dk, float* dv,
-                                     float* workspace, int B, int H, int N, int d, float scale, void* stream) {
+extern "C" int skp_flash_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
+                                      const float* dout, const float* lse, float* dq, float* dk, float* dv,
+                                      float* workspace, int B, int Bk, int H, int N, int Nk, int d, float scale,
+                                      void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return SKP_E_BADARG;
-    int rc = sa_check(B, H, N, d);
+    int rc = sa_check(B, Bk, H, N, Nk, d);
     if (rc) return rc;
-    dim3 grid((N + 127) / 128, H, B), block(256);
+    if (!sa_gen1()) {
+        rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, stream);
+        if (rc != -100) return rc;
+    }
+    const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
-    switch (d) {
-        case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 1, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
-        case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 2, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
-        case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 4, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
-        case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 5, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
-        case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 8, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
-        case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 10, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
-        default: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 20, 1, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, scale) break;
+    {
+        dim3 grid((N + 127) / 128, H, B), block(256);
+        switch (d) {
+            case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 1, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+            case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 2, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+            case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 4, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+            case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 5, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+            case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 8, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+            case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 10, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+            default: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 20, 1, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+        }
     }
     rc = skp_launch_status();
     if (rc) return rc;
+    dim3 grid((Nk + 127) / 128, H, B), block(256);
     switch (d) {
-        case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 1, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 2, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 4, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 5, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 8, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 10, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
-        default: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 20, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, scale) break;
+        case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 1, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 2, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 4, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 5, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 8, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 10, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        default: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 20, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
     }
     return skp_launch_status();
+}
+
+extern "C" int skp_self_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
+                                     int B, int H, int N, int d, float scale, void* stream) {
+    return skp_flash_attn_fwd_f32(q, k, v, out, lse, B, B, H, N, N, d, scale, stream);
+}
+
+extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
+                                     const float* dout, const float* lse, float* dq, float* dk, float* dv,
+                                     float* workspace, int B, int H, int N, int d, float scale, void* stream) {
+    return skp_flash_attn_bwd_f32(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, B, H, N, N, d, scale, stream);
 }

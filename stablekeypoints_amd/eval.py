@@ -62,9 +62,12 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
 
     Reference loop: per augmentation -> UNet forward -> collect_maps(indices, upsample_res=upscale_size) ->
     inverse-warp the maps and a ones-mask -> accumulate; result = sum/count with NaN -> 0.
-    Here all `augmentation_iterations // num_gpus` views go through the network as ONE batch (early exit,
-    fused map kernel); gather/resize/unwarp stay linear ops applied after the layer/head mean.
-    `thetas` [n,2,3] / `noise` [n,4,h,w] let a caller inject the random draws (parity tests)."""
+    Here all of this rank's views go through the network as ONE batch (early exit, fused map kernel);
+    gather/resize/unwarp stay linear ops applied after the layer/head mean.
+    Multi-GPU: the augmentations are sharded over the ranks -- each rank runs
+    `augmentation_iterations // (num_gpus * world_size)` views -- and the un-warped sum and the coverage count
+    ([K,S,S] each) are all-reduced before the division, so every rank returns the same averaged maps.
+    `thetas` [n,2,3] / `noise` [n,4,h,w] let a caller inject THIS rank's random draws (parity tests)."""
     import numpy as np
     from . import ptp_utils
     from ._maps import collect_maps_batched
@@ -77,7 +80,10 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     if isinstance(image, np.ndarray):
         image = torch.from_numpy(image).permute(2, 0, 1)
     image = image.to(device=dev, dtype=torch.float32)
-    n = augmentation_iterations // num_gpus
+    from . import dist as skp_dist
+    n = augmentation_iterations // (num_gpus * skp_dist.world_size())
+    if n < 1:
+        raise ValueError(f"augmentation_iterations ({augmentation_iterations}) is smaller than the data-parallel width")
     tr = RandomAffineWithInverse(degrees=augment_degrees, scale=augment_scale, translate=augment_translate)
     views = tr(image[None].repeat(n, 1, 1, 1), theta=thetas)
     ptp_utils.find_pred_noise(ldm, views, context.to(dev), noise_level=noise_level, device=dev, noise=noise,
@@ -87,6 +93,17 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     maps = F.interpolate(maps[:, idx], size=(upscale_size, upscale_size), mode="bilinear", align_corners=False)
     num = tr.inverse(torch.ones_like(maps)).sum(dim=0)
     tot = tr.inverse(maps).sum(dim=0)
+    return finish_augmented(tot, num)
+
+
+def finish_augmented(tot, num):
+    """eval.py:343-353 across ranks: SUM all-reduce of the un-warped map sum and of the coverage count (one exchange of
+    2 x [K,S,S] floats), then sum / count with 0/0 -> 0."""
+    from . import dist as skp_dist
+    if skp_dist.world_size() > 1:
+        both = torch.stack([tot, num])
+        skp_dist.allreduce_sum_(both)
+        tot, num = both[0], both[1]
     out = tot / num
     out[out != out] = 0
     return out

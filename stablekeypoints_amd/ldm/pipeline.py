@@ -132,19 +132,33 @@ class StableDiffusionPipeline:
         self.arch, self.synthetic_weights = arch, synthetic
 
     @staticmethod
-    def build(arch: str, seed=0, unet_kwargs=None):
+    def build(arch: str, seed=0, unet_kwargs=None, init_device=None):
+        """Module trees with seeded default inits.  `init_device=None`: parameters are drawn on the CPU (identical on
+        every box, and on CPU and GPU runs -- what the parity tests rely on).  `init_device="cuda:N"`: drawn directly
+        on that GPU from its own seeded generator (identical on every rank of a job, different numbers from the CPU
+        draw): N ranks of a multi-GPU run do not contend for the host cores with N x 3.4 GB of CPU-side init."""
         cfg = ARCHS[arch]
+        on_gpu = init_device is not None and torch.device(init_device).type == "cuda"
         gen_state = torch.random.get_rng_state()
+        cuda_state = torch.cuda.get_rng_state(init_device) if on_gpu else None
         torch.manual_seed(seed)
         try:
-            unet = UNet2DConditionModel(**(unet_kwargs if unet_kwargs is not None else cfg["unet"]))
-            vae = AutoencoderKL(**cfg["vae"])
+            if on_gpu:
+                with torch.device(init_device):
+                    unet = UNet2DConditionModel(**(unet_kwargs if unet_kwargs is not None else cfg["unet"]))
+                    vae = AutoencoderKL(**cfg["vae"])
+            else:
+                unet = UNet2DConditionModel(**(unet_kwargs if unet_kwargs is not None else cfg["unet"]))
+                vae = AutoencoderKL(**cfg["vae"])
         finally:
             torch.random.set_rng_state(gen_state)
+            if on_gpu:
+                torch.cuda.set_rng_state(cuda_state, init_device)
         return unet, vae
 
     @classmethod
-    def from_pretrained(cls, type="sd-legacy/stable-diffusion-v1-5", use_auth_token=None, scheduler=None, seed=0):
+    def from_pretrained(cls, type="sd-legacy/stable-diffusion-v1-5", use_auth_token=None, scheduler=None, seed=0,
+                        init_device=None):
         name = str(type)
         sched = scheduler if scheduler is not None else DDIMScheduler()
         if os.path.isdir(name):
@@ -169,7 +183,7 @@ class StableDiffusionPipeline:
             arch = guess_arch(name)
             warnings.warn(f"'{name}' not found locally: building the {arch} architecture with SEEDED SYNTHETIC weights "
                           "(SKP_ALLOW_SYNTHETIC=1) -- keypoints optimised against it are meaningless", stacklevel=2)
-        unet, vae = cls.build(arch, seed)
+        unet, vae = cls.build(arch, seed, init_device=init_device)
         unet.eval(); vae.eval()
         return cls(unet, vae, sched, arch, synthetic=True)
 

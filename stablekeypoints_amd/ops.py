@@ -298,7 +298,9 @@ CROSS_ATTN_MAX_T = 128
 
 
 def cross_attn_supported(C: int, heads: int, T: int) -> bool:
-    return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS and T <= CROSS_ATTN_MAX_T
+    """Every key count is served: T <= 128 by the in-register softmax kernel, more tokens (the reference default is
+    --num_tokens 500, main.py:77-79) by the key-tiled online-softmax (flash) kernels."""
+    return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS
 
 
 class CrossAttnFn(torch.autograd.Function):
@@ -340,6 +342,8 @@ class CrossAttnFn(torch.autograd.Function):
 
 
 def cross_attention(q, k, v, heads: int, scale: float):
+    if k.shape[1] > CROSS_ATTN_MAX_T:
+        return FlashAttnFn.apply(q, k, v, int(heads), float(scale))
     return CrossAttnFn.apply(q, k, v, int(heads), float(scale))
 
 
@@ -398,17 +402,20 @@ def self_attn_supported(C: int, heads: int) -> bool:
     return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS
 
 
-class SelfAttnFn(torch.autograd.Function):
-    """out = merge_heads(softmax(scale q k^T) v) for q, k, v [B,N,C]; scores never materialised."""
+class FlashAttnFn(torch.autograd.Function):
+    """out = merge_heads(softmax(scale q k^T) v); q [B,N,C], k, v [Bk,Nk,C] with Bk in {1,B}; key-tiled online
+    softmax, scores never materialised.  Self-attention is the Bk == B, Nk == N case."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads: int, scale: float):
         q, k, v = _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
         B, Nq, C = q.shape
+        Bk, Nk, _ = k.shape
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
-        N.check(N.lib().skp_self_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                                              B, heads, Nq, C // heads, float(scale), _stream()), "skp_self_attn_fwd_f32")
+        N.check(N.lib().skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                               B, Bk, heads, Nq, Nk, C // heads, float(scale), _stream()),
+                "skp_flash_attn_fwd_f32")
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.meta = (heads, float(scale))
         return out
@@ -419,16 +426,24 @@ class SelfAttnFn(torch.autograd.Function):
         heads, scale = ctx.meta
         dout = _dev(dout, "dout")
         B, Nq, C = q.shape
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        Bk, Nk, _ = k.shape
+        dq = torch.empty_like(q)
+        dk = torch.empty(B, Nk, C, device=q.device, dtype=torch.float32)
+        dv = torch.empty_like(dk)
         ws = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
-        N.check(N.lib().skp_self_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
-                                              lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(),
-                                              B, heads, Nq, C // heads, scale, _stream()), "skp_self_attn_bwd_f32")
+        N.check(N.lib().skp_flash_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                               lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(),
+                                               B, Bk, heads, Nq, Nk, C // heads, scale, _stream()), "skp_flash_attn_bwd_f32")
+        if Bk == 1 and B > 1:
+            dk, dv = dk.sum(dim=0, keepdim=True), dv.sum(dim=0, keepdim=True)
         return dq, dk, dv, None, None
 
 
+SelfAttnFn = FlashAttnFn
+
+
 def self_attention(q, k, v, heads: int, scale: float):
-    return SelfAttnFn.apply(q, k, v, int(heads), float(scale))
+    return FlashAttnFn.apply(q, k, v, int(heads), float(scale))
 
 
 class AddBiasResidualFn(torch.autograd.Function):

@@ -101,7 +101,9 @@ def image_losses(attn_map, attn_map_t, theta_row, args):
     am, order = token_order(attn_map, strategy, ns, sigma)
     am_t, _ = ops.token_stats(attn_map_t, num_subjects=1, sigma=sigma, want_kl=False)
     n_cand = min(args.furthest_point_num_samples, attn_map.shape[0])
-    _, sel = ops.select_tokens(order, am_t[0], attn_map.shape[-1], n_cand, args.top_k)
+    # the reference's greedy loop stops adding once every candidate is chosen (ptp_utils.py:142-157), i.e. it returns
+    # min(top_k, n_cand) tokens
+    _, sel = ops.select_tokens(order, am_t[0], attn_map.shape[-1], n_cand, min(args.top_k, n_cand))
     sharp, equiv = ops.fused_losses(attn_map, attn_map_t, sel, am, theta_row, sigma, ns)
     return sharp, equiv, sel
 

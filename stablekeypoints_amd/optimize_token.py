@@ -15,11 +15,15 @@ from .ldm.pipeline import StableDiffusionPipeline
 from .ldm.scheduler import DDIMScheduler
 
 
-def load_ldm(device, type="CompVis/stable-diffusion-v1-4", feature_upsample_res=256, my_token=None):
+def load_ldm(device, type="CompVis/stable-diffusion-v1-4", feature_upsample_res=256, my_token=None,
+             init_on_device=False):
+    """optimize_token.py:24-78.  `init_on_device` (extension, synthetic weights only): draw the seeded weights directly
+    on `device` instead of on the host (multi-GPU start-up; see StableDiffusionPipeline.build)."""
     scheduler = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                               clip_sample=False, set_alpha_to_one=False)
     scheduler.set_timesteps(50)                                   # NUM_DDIM_STEPS, optimize_token.py:33-34
-    ldm = StableDiffusionPipeline.from_pretrained(type, use_auth_token=my_token, scheduler=scheduler).to(device)
+    ldm = StableDiffusionPipeline.from_pretrained(type, use_auth_token=my_token, scheduler=scheduler,
+                                                  init_device=device if init_on_device else None).to(device)
     dev = torch.device(device)
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())

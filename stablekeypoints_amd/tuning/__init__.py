@@ -23,7 +23,11 @@ def enable() -> bool:
         tunable.enable(True)
         tunable.tuning_enable(os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") == "1")
         if os.environ.get("PYTORCH_TUNABLEOP_TUNING", "0") != "1":
-            tunable.write_file_on_exit(False)           # read-only use: no exit-time dump anywhere
+            # read-only use: nothing may be left behind at exit
+            if hasattr(tunable, "write_file_on_exit"):
+                tunable.write_file_on_exit(False)
+            else:
+                tunable.set_filename(os.devnull)        # this torch always dumps at exit: send it nowhere
         if os.path.exists(path):
             tunable.read_file(path)
         _done = True

@@ -51,6 +51,40 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
         torch.testing.assert_close(a[step], ctx.detach(), rtol=1e-6, atol=1e-7)
 
 
+def _aug_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from stablekeypoints_amd import dist as D
+    from stablekeypoints_amd.eval import finish_augmented
+    D.init_from_env("gloo")
+    g = torch.Generator().manual_seed(3)
+    cover = (torch.rand(4, 2, 5, 5, generator=g) > 0.6).float()                    # pixels a view covers
+    vals = torch.rand(4, 2, 5, 5, generator=g) * cover                             # uncovered pixels contribute 0
+    tot, num = vals[rank * 2:(rank + 1) * 2].sum(0), cover[rank * 2:(rank + 1) * 2].sum(0)   # this rank's two views
+    torch.save(finish_augmented(tot, num), os.path.join(out, f"a{rank}.pt"))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_augmented_inference_reduction(tmp_path):
+    """augmentations sharded over ranks, one all-reduce of (sum, count): same maps on every rank and
+    equal to the single-process result over all views; 0/0 pixels become 0."""
+    port = 29300 + (os.getpid() % 150)
+    mp.spawn(_aug_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "a0.pt"), torch.load(tmp_path / "a1.pt")
+    assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(3)
+    cover = (torch.rand(4, 2, 5, 5, generator=g) > 0.6).float()
+    vals = torch.rand(4, 2, 5, 5, generator=g) * cover
+    tot, num = vals.sum(0), cover.sum(0)
+    assert (num == 0).any()                                     # some pixels are covered by no view at all: 0/0 -> 0
+    ref = tot / num
+    ref[ref != ref] = 0
+    torch.testing.assert_close(a, ref, rtol=1e-6, atol=1e-7)
+    assert torch.isfinite(a).all()
+
+
 def test_shard_indices_partition():
     from stablekeypoints_amd.dist import shard_indices
     perm = list(range(11))

@@ -183,6 +183,16 @@ def test_bench_two_ranks_one_gpu_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["scaling"] == "weak" and d["steps"] == 2
+    assert d["collective_check"]["ok"] and d["collective_check"]["ranks_seen"] == 2
+    assert d["collective_check"]["embedding_identical_on_all_ranks"] is True
+    # strong scaling: the global batch stays at --global-batch, each rank takes half
+    cmd = cmd[:cmd.index("--master-port") + 1] + [str(29900 + os.getpid() % 90)] + cmd[cmd.index("--master-port") + 2:]
+    out = subprocess.run(cmd + ["--scaling", "strong", "--global-batch", "4"], capture_output=True, text=True, timeout=600,
+                         env=env, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 4 and d["config"]["images_per_rank"] == 2
 
 
 def test_sd_shapes_maps_with_winograd_convs_match_library_convs():

@@ -6,7 +6,7 @@ import torch
 
 from oracle import ref_path as R
 from oracle.fixtures import (HOOK_CASES, STACK_CASE, SEL_CASE, E2E_CASE, attention_weights, seeded,
-                             selection_maps)
+                             selection_maps, sharp_entropy_maps)
 
 TOL = dict(rtol=2e-5, atol=2e-7)
 
@@ -92,12 +92,6 @@ def test_g3_selection(golden):
         assert torch.equal(top, t(g[f"top_k_gaussian_ns{ns}"]))
         fps = R.furthest_point_sampling(maps_t, s["top_k"], top)
         assert torch.equal(fps, t(g[f"fps_ns{ns}"]))
-
-
-def sharp_entropy_maps(maps):
-    """The second map family of G3b (oracle/gen_golden.py): entropies spread far apart."""
-    n = maps.shape[0]
-    return torch.softmax((maps * 40.0).view(n, -1) * torch.linspace(0.2, 3.0, n)[:, None], dim=-1).view_as(maps).contiguous()
 
 
 def test_g3b_entropy_strategy(golden):
