@@ -34,9 +34,52 @@ struct FA2 {
     static constexpr int U = (KT * Q4 + 255) / 256;   // float4 per thread and staged matrix
 };
 
-// global -> registers (rows beyond `rows_left` read as zero)
+// Staging of a 64-row tile: thread `tid` moves float4 number tid + 256 u of the tile.  The row / column split of that
+// index is loop-invariant, so it is done once (FA2Stage) -- inside the tile loop a fetch is one load per float4.
 template <int D>
-__device__ __forceinline__ void fa2_fetch(f32x4 (&r)[FA2<D>::U], const float* __restrict__ src, int rows_left, int C, int tid) {
+struct FA2Stage {
+    int goff[FA2<D>::U];      // element offset inside the global tile (row * C + 4 * c4), -1 = this thread has no slot u
+    int loff[FA2<D>::U];      // float offset inside the LDS tile
+    __device__ __forceinline__ void init(int C, int tid) {
+        using F = FA2<D>;
+#pragma unroll
+        for (int u = 0; u < F::U; ++u) {
+            const int idx = tid + 256 * u;
+            const int t = idx / F::Q4, c4 = idx - t * F::Q4;
+            const bool ok = idx < F::KT * F::Q4;
+            goff[u] = t * C + c4 * 4;
+            loff[u] = ok ? t * F::LDK + c4 * 4 : -1;
+        }
+    }
+};
+
+// global -> registers.  FULL: every row of the tile exists (no per-row test); else rows >= rows_left read as zero.
+template <int D, bool FULL>
+__device__ __forceinline__ void fa2_fetch(f32x4 (&r)[FA2<D>::U], const float* __restrict__ src, const FA2Stage<D>& st, int rows_left,
+                                          int tid) {
+    using F = FA2<D>;
+#pragma unroll
+    for (int u = 0; u < F::U; ++u) {
+        if (FULL) {
+            if (st.loff[u] >= 0) r[u] = *(const f32x4*)(src + st.goff[u]);
+        } else {                                                // ragged tile (once per kernel): redo the row split here
+            r[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (st.loff[u] >= 0 && (tid + 256 * u) / F::Q4 < rows_left) r[u] = *(const f32x4*)(src + st.goff[u]);
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void fa2_put(float* __restrict__ dst, const f32x4 (&r)[FA2<D>::U], const FA2Stage<D>& st) {
+    using F = FA2<D>;
+#pragma unroll
+    for (int u = 0; u < F::U; ++u)
+        if (st.loff[u] >= 0) *(f32x4*)(dst + st.loff[u]) = r[u];
+}
+
+// on-the-fly variant (index split recomputed per tile) kept for A/B timing
+template <int D>
+__device__ __forceinline__ void fa2_fetch_otf(f32x4 (&r)[FA2<D>::U], const float* __restrict__ src, int rows_left, int C, int tid) {
     using F = FA2<D>;
 #pragma unroll
     for (int u = 0; u < F::U; ++u) {
@@ -46,9 +89,8 @@ __device__ __forceinline__ void fa2_fetch(f32x4 (&r)[FA2<D>::U], const float* __
         if (idx < F::KT * F::Q4 && t < rows_left) r[u] = *(const f32x4*)(src + (size_t)t * C + c4 * 4);
     }
 }
-
 template <int D>
-__device__ __forceinline__ void fa2_put(float* __restrict__ dst, const f32x4 (&r)[FA2<D>::U], int tid) {
+__device__ __forceinline__ void fa2_put_otf(float* __restrict__ dst, const f32x4 (&r)[FA2<D>::U], int tid) {
     using F = FA2<D>;
 #pragma unroll
     for (int u = 0; u < F::U; ++u) {
@@ -56,6 +98,27 @@ __device__ __forceinline__ void fa2_put(float* __restrict__ dst, const f32x4 (&r
         const int t = idx / F::Q4, c4 = idx - t * F::Q4;
         if (idx < F::KT * F::Q4) *(f32x4*)(dst + t * F::LDK + c4 * 4) = r[u];
     }
+}
+
+// next tile (rows [r0, r0 + 64) of a matrix with `total` rows): full tiles take the test-free path
+template <int D>
+__device__ __forceinline__ void fa2_fetch_tile(f32x4 (&r)[FA2<D>::U], const float* __restrict__ base, int C, int r0, int total,
+                                               const FA2Stage<D>& st, int tid) {
+    const float* src = base + (size_t)r0 * C;
+    if (r0 + FA2<D>::KT <= total) fa2_fetch<D, true>(r, src, st, 0, tid);
+    else fa2_fetch<D, false>(r, src, st, total - r0, tid);
+}
+
+template <int D, bool PRE>
+__device__ __forceinline__ void fa2_stage_in(f32x4 (&r)[FA2<D>::U], const float* __restrict__ base, int C, int r0, int total,
+                                             const FA2Stage<D>& st, int tid) {
+    if (PRE) fa2_fetch_tile<D>(r, base, C, r0, total, st, tid);
+    else fa2_fetch_otf<D>(r, base + (size_t)r0 * C, total - r0, C, tid);
+}
+template <int D, bool PRE>
+__device__ __forceinline__ void fa2_stage_out(float* __restrict__ dst, const f32x4 (&r)[FA2<D>::U], const FA2Stage<D>& st, int tid) {
+    if (PRE) fa2_put<D>(dst, r, st);
+    else fa2_put_otf<D>(dst, r, tid);
 }
 
 // acc[kt][nt] += X[16 kt + i16][:] . Y_nt[:]   (X rows from LDS, Y in registers as f32x2 fragments [D8])
@@ -98,27 +161,21 @@ __device__ __forceinline__ void fa2_colacc(const float* __restrict__ X, const f3
         }
 }
 
-// Reductions over the four lanes (g = 0..3) that share a column.  v_permlane16_swap / v_permlane32_swap (gfx950) exchange
-// 16-lane rows / 32-lane halves between two registers on the VALU: with both operands = v the two results hold
-// {v[lane], v[lane ^ 16]} (resp. ^ 32) in every lane -- no LDS round trip as with ds_bpermute.
-typedef unsigned fa2_u32x2 __attribute__((ext_vector_type(2)));
+// Reductions over the four lanes (g = 0..3) that share a column.
+// (v_permlane16_swap / v_permlane32_swap do the same exchange on the VALU; measured 1 % slower here than ds_bpermute)
 __device__ __forceinline__ float fa2_max4(float v) {
-    fa2_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 __device__ __forceinline__ float fa2_sum4(float v) {
-    fa2_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
 }
 
 }  // namespace
 
 // grid (ceil(N / (64 NQT)), H, B), 256 threads; wave w owns queries [blk*64*NQT + w*16*NQT, +16 NQT)
-template <int D, int NQT, int MINW>
+template <int D, int NQT, int MINW, int OPT>
 __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, float* __restrict__ out,
                                                           float* __restrict__ lse, int H, int N, int Nk, int kvb, float scale) {
@@ -151,11 +208,27 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
 #pragma unroll
     for (int nt = 0; nt < NQT; ++nt) { mrun[nt] = -INFINITY; lpart[nt] = 0.f; }
 
+    // Row sums through the matrix pipe: when D is not a multiple of 16 the last 16-channel tile of P.V has idle rows.
+    // Column D of the staged V tile (LDS padding, never written by the staging) is set to 1, so row D of O^T accumulates
+    // sum_t P[n][t] -- rescaled by alpha together with O -- and the softmax needs no VALU adds for the running sum.
+    constexpr bool ONES = (D % 16) != 0 && (OPT & 2);
+    constexpr int LCT = D / 16, LG = (D % 16) / 4, LR = D % 4;   // where row D of O^T lives: tile, lane group, register
+    constexpr bool PRE = (OPT & 4) != 0;                        // loop-invariant staging offsets precomputed
+    FA2Stage<D> stg;
+    if (PRE) stg.init(C, tid);
     f32x4 kr[F::U], vr[F::U];
-    fa2_fetch<D>(kr, kg, Nk, C, tid);
-    fa2_fetch<D>(vr, vg, Nk, C, tid);
-    fa2_put<D>(smem, kr, tid);
-    fa2_put<D>(smem + F::TILE, vr, tid);
+    if (PRE) {
+        fa2_fetch_tile<D>(kr, kg, C, 0, Nk, stg, tid);
+        fa2_fetch_tile<D>(vr, vg, C, 0, Nk, stg, tid);
+        fa2_put<D>(smem, kr, stg);
+        fa2_put<D>(smem + F::TILE, vr, stg);
+    } else {
+        fa2_fetch_otf<D>(kr, kg, Nk, C, tid);
+        fa2_fetch_otf<D>(vr, vg, Nk, C, tid);
+        fa2_put_otf<D>(smem, kr, tid);
+        fa2_put_otf<D>(smem + F::TILE, vr, tid);
+    }
+    if (ONES && tid < 128) smem[(tid >> 6) * 2 * F::TILE + F::TILE + (tid & 63) * F::LDK + D] = 1.0f;
     __syncthreads();
 
     int cur = 0;
@@ -164,8 +237,13 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
         const float* Vs = Ks + F::TILE;
         const bool more = kt0 + F::KT < Nk;
         if (more) {                                             // next tile: global loads in flight under this tile's MFMAs
-            fa2_fetch<D>(kr, kg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
-            fa2_fetch<D>(vr, vg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
+            if (PRE) {
+                fa2_fetch_tile<D>(kr, kg, C, kt0 + F::KT, Nk, stg, tid);
+                fa2_fetch_tile<D>(vr, vg, C, kt0 + F::KT, Nk, stg, tid);
+            } else {
+                fa2_fetch_otf<D>(kr, kg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
+                fa2_fetch_otf<D>(vr, vg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
+            }
         }
         f32x4 s[4][NQT];
 #pragma unroll
@@ -185,10 +263,10 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
                     }
         }
 #pragma unroll
-        for (int nt = 0; nt < NQT; ++nt) {
-            float tm = -INFINITY;
+        for (int nt = 0; nt < NQT; ++nt) {                      // one query block after the other: the next block's max
+            float tm = fmaxf(fmaxf(s[0][nt][0], s[0][nt][1]), fmaxf(s[0][nt][2], s[0][nt][3]));   // reduction overlaps this block's exps
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) tm = fmaxf(tm, fmaxf(fmaxf(s[kt][nt][0], s[kt][nt][1]), fmaxf(s[kt][nt][2], s[kt][nt][3])));
+            for (int kt = 1; kt < 4; ++kt) tm = fmaxf(tm, fmaxf(fmaxf(s[kt][nt][0], s[kt][nt][1]), fmaxf(s[kt][nt][2], s[kt][nt][3])));
             tm = fa2_max4(tm);
             const float mn = fmaxf(mrun[nt], tm);
             const float alpha = __builtin_amdgcn_exp2f(mrun[nt] - mn);     // first tile: exp2(-inf) = 0
@@ -199,24 +277,26 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s[kt][nt][r] = __builtin_amdgcn_exp2f(s[kt][nt][r] - mn);
-                    rs += s[kt][nt][r];
+                    if (!ONES) rs += s[kt][nt][r];
                 }
-            lpart[nt] = lpart[nt] * alpha + rs;
+            if (!ONES) lpart[nt] = lpart[nt] * alpha + rs;
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) o[ct][nt] *= alpha;
         }
         fa2_colacc<D, 4, NQT>(Vs, s, o, i16, g);
         if (more) {
             float* nb = smem + (cur ^ 1) * 2 * F::TILE;
-            fa2_put<D>(nb, kr, tid);
-            fa2_put<D>(nb + F::TILE, vr, tid);
+            if (PRE) { fa2_put<D>(nb, kr, stg); fa2_put<D>(nb + F::TILE, vr, stg); }
+            else { fa2_put_otf<D>(nb, kr, tid); fa2_put_otf<D>(nb + F::TILE, vr, tid); }
         }
         __syncthreads();
         cur ^= 1;
     }
 #pragma unroll
     for (int nt = 0; nt < NQT; ++nt) {
-        const float l = fa2_sum4(lpart[nt]);
+        float l;
+        if (ONES) l = __shfl(o[LCT][nt][LR], 16 * LG + i16, 64);          // row D of O^T = sum_t P[n][t]
+        else l = fa2_sum4(lpart[nt]);
         const float inv = 1.0f / l;
         const int n = nrow[nt];
         if (n < N) {
@@ -239,7 +319,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
 //               dV^T[c][t] += sum_n dO[n][c] P[n][t],  dK^T[c][t] += sum_n Q[n][c] dS[n][t].
 // In both, the score registers are the B operand of the accumulating product as they are (k-slot g <-> row 4 g + r).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int NQT, int MINW>
+template <int D, int NQT, int MINW, bool PRE>
 __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ out,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
@@ -283,11 +363,13 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
 #pragma unroll
         for (int nt = 0; nt < NQT; ++nt) dqa[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    FA2Stage<D> stg;
+    if (PRE) stg.init(C, tid);
     f32x4 kr[F::U], vr[F::U];
-    fa2_fetch<D>(kr, kg, Nk, C, tid);
-    fa2_fetch<D>(vr, vg, Nk, C, tid);
-    fa2_put<D>(smem, kr, tid);
-    fa2_put<D>(smem + F::TILE, vr, tid);
+    fa2_stage_in<D, PRE>(kr, kg, C, 0, Nk, stg, tid);
+    fa2_stage_in<D, PRE>(vr, vg, C, 0, Nk, stg, tid);
+    fa2_stage_out<D, PRE>(smem, kr, stg, tid);
+    fa2_stage_out<D, PRE>(smem + F::TILE, vr, stg, tid);
     __syncthreads();
 
     int cur = 0;
@@ -296,8 +378,8 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
         const float* Vs = Ks + F::TILE;
         const bool more = kt0 + F::KT < Nk;
         if (more) {
-            fa2_fetch<D>(kr, kg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
-            fa2_fetch<D>(vr, vg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
+            fa2_stage_in<D, PRE>(kr, kg, C, kt0 + F::KT, Nk, stg, tid);
+            fa2_stage_in<D, PRE>(vr, vg, C, kt0 + F::KT, Nk, stg, tid);
         }
         f32x4 s[4][NQT], dp[4][NQT];
 #pragma unroll
@@ -306,22 +388,29 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
             for (int nt = 0; nt < NQT; ++nt) { s[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         fa2_rowdot<D, 4, NQT>(Ks, qf, s, i16, g);
         fa2_rowdot<D, 4, NQT>(Vs, dof, dp, i16, g);
-        const int left = Nk - kt0;                              // keys beyond the end contribute nothing
+        if (kt0 + F::KT > Nk) {                                 // ragged last tile: keys beyond the end contribute nothing
+            const int left = Nk - kt0;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * kt + 4 * g + r >= left) {
+#pragma unroll
+                        for (int nt = 0; nt < NQT; ++nt) s[kt][nt][r] = -INFINITY;      // P = exp2(-inf) = 0
+                    }
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int nt = 0; nt < NQT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pr = __builtin_amdgcn_exp2f(s[kt][nt][r] - lse2[nt]);
-                    if (16 * kt + 4 * g + r >= left) pr = 0.f;
-                    s[kt][nt][r] = pr * (dp[kt][nt][r] - dsum[nt]);     // dS
-                }
+                for (int r = 0; r < 4; ++r)
+                    s[kt][nt][r] = __builtin_amdgcn_exp2f(s[kt][nt][r] - lse2[nt]) * (dp[kt][nt][r] - dsum[nt]);     // dS
         fa2_colacc<D, 4, NQT>(Ks, s, dqa, i16, g);
         if (more) {
             float* nb = smem + (cur ^ 1) * 2 * F::TILE;
-            fa2_put<D>(nb, kr, tid);
-            fa2_put<D>(nb + F::TILE, vr, tid);
+            fa2_stage_out<D, PRE>(nb, kr, stg, tid);
+            fa2_stage_out<D, PRE>(nb + F::TILE, vr, stg, tid);
         }
         __syncthreads();
         cur ^= 1;
@@ -341,7 +430,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
 }
 
 // grid (ceil(Nk / (64 NTT)), H, B); wave w owns keys [blk*64*NTT + w*16*NTT, +16 NTT).  LDS per buffer: Q | dO | lse2[64] | D[64]
-template <int D, int NTT, int MINW>
+template <int D, int NTT, int MINW, bool PRE>
 __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                     const float* __restrict__ v, const float* __restrict__ dout,
                                                                     const float* __restrict__ lse, const float* __restrict__ Dbuf,
@@ -381,15 +470,18 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
     // per-row statistics of a query tile: thread tid < 64 carries lse2, 64 <= tid < 128 carries D
     auto fetch_stats = [&](int q0) -> float {
         const int i = tid & 63, n = q0 + i;
-        if (tid >= 128 || n >= N) return 0.f;
+        if (tid >= 128) return 0.f;
+        if (n >= N) return tid < 64 ? INFINITY : 0.f;            // missing rows: lse2 = +inf => their P is exactly 0
         return tid < 64 ? lse[soff + n] * SKP_LOG2E : Dbuf[soff + n];
     };
+    FA2Stage<D> stg;
+    if (PRE) stg.init(C, tid);
     f32x4 qr[F::U], dr[F::U];
     float st = fetch_stats(0);
-    fa2_fetch<D>(qr, qg, N, C, tid);
-    fa2_fetch<D>(dr, dog, N, C, tid);
-    fa2_put<D>(smem, qr, tid);
-    fa2_put<D>(smem + F::TILE, dr, tid);
+    fa2_stage_in<D, PRE>(qr, qg, C, 0, N, stg, tid);
+    fa2_stage_in<D, PRE>(dr, dog, C, 0, N, stg, tid);
+    fa2_stage_out<D, PRE>(smem, qr, stg, tid);
+    fa2_stage_out<D, PRE>(smem + F::TILE, dr, stg, tid);
     if (tid < 128) smem[2 * F::TILE + tid] = st;
     __syncthreads();
 
@@ -401,8 +493,8 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
         const bool more = q0 + F::KT < N;
         if (more) {
             st = fetch_stats(q0 + F::KT);
-            fa2_fetch<D>(qr, qg + (size_t)(q0 + F::KT) * C, N - q0 - F::KT, C, tid);
-            fa2_fetch<D>(dr, dog + (size_t)(q0 + F::KT) * C, N - q0 - F::KT, C, tid);
+            fa2_stage_in<D, PRE>(qr, qg, C, q0 + F::KT, N, stg, tid);
+            fa2_stage_in<D, PRE>(dr, dog, C, q0 + F::KT, N, stg, tid);
         }
         f32x4 s[4][NTT], dp[4][NTT];
 #pragma unroll
@@ -411,29 +503,26 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
             for (int tt = 0; tt < NTT; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         fa2_rowdot<D, 4, NTT>(Qs, kf, s, i16, g);               // S[n][t]: rows = staged queries, lane = key
         fa2_rowdot<D, 4, NTT>(dOs, vf, dp, i16, g);             // dP[n][t] = dO[n] . V[t]
-        const int left = N - q0;
+        // rows beyond N (ragged last tile) were staged as zeros with lse2 = +inf  =>  P = exp2(0 - inf) = 0, dS = 0
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const f32x4 l4 = *(const f32x4*)(Ls + 16 * nt + 4 * g);
             const f32x4 d4 = *(const f32x4*)(Ls + 64 + 16 * nt + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = 16 * nt + 4 * g + r < left;
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int tt = 0; tt < NTT; ++tt) {
-                    float pr = __builtin_amdgcn_exp2f(s[nt][tt][r] - l4[r]);
-                    if (!ok) pr = 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(s[nt][tt][r] - l4[r]);
                     s[nt][tt][r] = pr;                                   // P
                     dp[nt][tt][r] = pr * (dp[nt][tt][r] - d4[r]);        // dS
                 }
-            }
         }
         fa2_colacc<D, 4, NTT>(dOs, s, dva, i16, g);             // dV^T[c][t] += sum_n dO[n][c] P[n][t]
         fa2_colacc<D, 4, NTT>(Qs, dp, dka, i16, g);             // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
         if (more) {
             float* nb = smem + (cur ^ 1) * BUF;
-            fa2_put<D>(nb, qr, tid);
-            fa2_put<D>(nb + F::TILE, dr, tid);
+            fa2_stage_out<D, PRE>(nb, qr, stg, tid);
+            fa2_stage_out<D, PRE>(nb + F::TILE, dr, stg, tid);
             if (tid < 128) nb[2 * F::TILE + tid] = st;
         }
         __syncthreads();
@@ -459,19 +548,19 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int NQT, int MINW>
+template <int D, int NQT, int MINW, int OPT>
 static int fa2_launch_fwd(const float* q, const float* k, const float* v, float* out, float* lse, int B, int H, int N,
                           int Nk, int kvb, float scale, hipStream_t st) {
     using F = FA2<D>;
     const size_t lds = (size_t)4 * F::TILE * sizeof(float);
     static bool attr = false;
     if (!attr && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_fwd_kernel<D, NQT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_fwd_kernel<D, NQT, MINW, OPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     dim3 grid((N + 64 * NQT - 1) / (64 * NQT), H, B), block(256);
-    hipLaunchKernelGGL((skp_fa2_fwd_kernel<D, NQT, MINW>), grid, block, lds, st, q, k, v, out, lse, H, N, Nk, kvb, scale);
+    hipLaunchKernelGGL((skp_fa2_fwd_kernel<D, NQT, MINW, OPT>), grid, block, lds, st, q, k, v, out, lse, H, N, Nk, kvb, scale);
     return skp_launch_status();
 }
 
@@ -482,19 +571,31 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
     hipStream_t st = (hipStream_t)stream;
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
+    const char* eo = getenv("SKP_FA2_OPT");
+    const int opt = eo ? atoi(eo) : 6;
+#define FA2_FWD(DV, NQ, W, O) return fa2_launch_fwd<DV, NQ, W, O>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st)
+    // OPT bits: 2 = row sums through the idle MFMA rows (D % 16 != 0), 4 = precomputed staging offsets.  Measured
+    // (profiles/r02_flash_attn.md): 64 queries per wave wins where the grid still fills the chip twice; the precomputed
+    // offsets win at D = 40 / 64 and lose at D = 80.
+    const bool big = (long)((N + 255) / 256) * H * B >= 512;
     switch (d) {
         case 40:
-            if (variant == 1) return fa2_launch_fwd<40, 2, 3>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
-            if (variant == 2) return fa2_launch_fwd<40, 4, 2>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
-            if (variant == 3) return fa2_launch_fwd<40, 1, 4>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
-            return fa2_launch_fwd<40, 2, 2>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
-        case 64: return fa2_launch_fwd<64, 2, 2>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
-        case 80: return fa2_launch_fwd<80, 2, 2>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
+            if (variant == 1 || (variant == 0 && !big)) { if (opt == 0) FA2_FWD(40, 2, 2, 0); if (opt == 4) FA2_FWD(40, 2, 2, 4); FA2_FWD(40, 2, 2, 6); }
+            if (opt == 0) FA2_FWD(40, 4, 2, 0);
+            if (opt == 4) FA2_FWD(40, 4, 2, 4);
+            FA2_FWD(40, 4, 2, 6);
+        case 64:                                                // (64 queries per wave spills at this head size)
+            if (opt == 0) FA2_FWD(64, 2, 2, 0);
+            FA2_FWD(64, 2, 2, 4);
+        case 80:
+            if (opt == 4) FA2_FWD(80, 2, 2, 4);
+            FA2_FWD(80, 2, 2, 0);
         default: return -100;
     }
+#undef FA2_FWD
 }
 
-template <int D, int NQ, int MINWQ, int NT, int MINWT>
+template <int D, int NQ, int MINWQ, int NT, int MINWT, bool PRE>
 static int fa2_launch_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                           const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk, int kvb,
                           float scale, hipStream_t st) {
@@ -502,18 +603,18 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
     const size_t lds_q = (size_t)4 * F::TILE * sizeof(float), lds_kv = (size_t)2 * (2 * F::TILE + 128) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_dq_kernel<D, NQ, MINWQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_dq_kernel<D, NQ, MINWQ, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)skp_fa2_bwd_dkv_kernel<D, NT, MINWT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        e = hipFuncSetAttribute((const void*)skp_fa2_bwd_dkv_kernel<D, NT, MINWT, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
     dim3 block(256);
-    hipLaunchKernelGGL((skp_fa2_bwd_dq_kernel<D, NQ, MINWQ>), dim3((N + 64 * NQ - 1) / (64 * NQ), H, B), block, lds_q, st,
+    hipLaunchKernelGGL((skp_fa2_bwd_dq_kernel<D, NQ, MINWQ, PRE>), dim3((N + 64 * NQ - 1) / (64 * NQ), H, B), block, lds_q, st,
                        q, k, v, out, dout, lse, dq, ws, H, N, Nk, kvb, scale);
     int rc = skp_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL((skp_fa2_bwd_dkv_kernel<D, NT, MINWT>), dim3((Nk + 64 * NT - 1) / (64 * NT), H, B), block, lds_kv, st,
+    hipLaunchKernelGGL((skp_fa2_bwd_dkv_kernel<D, NT, MINWT, PRE>), dim3((Nk + 64 * NT - 1) / (64 * NT), H, B), block, lds_kv, st,
                        q, k, v, dout, lse, ws, dk, dv, H, N, Nk, kvb, scale);
     return skp_launch_status();
 }
@@ -526,20 +627,21 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
     hipStream_t st = (hipStream_t)stream;
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
-#define FA2_BWD(DV, NQ, WQ, NT, WT) \
-    return fa2_launch_bwd<DV, NQ, WQ, NT, WT>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
+#define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
+    return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
     switch (d) {
         case 40:
-            if (variant == 1) FA2_BWD(40, 1, 3, 1, 3);
-            if (variant == 2) FA2_BWD(40, 2, 2, 1, 3);
-            FA2_BWD(40, 2, 2, 2, 2);
+            if (variant == 1) FA2_BWD(40, 1, 3, 1, 3, true);
+            if (variant == 2) FA2_BWD(40, 2, 2, 2, 2, false);
+            FA2_BWD(40, 2, 2, 2, 2, true);
         case 64:
-            if (variant == 1) FA2_BWD(64, 2, 2, 2, 1);
-            if (variant == 2) FA2_BWD(64, 1, 2, 1, 2);
-            FA2_BWD(64, 2, 2, 1, 2);
-        case 80:
-            if (variant == 1) FA2_BWD(80, 2, 1, 2, 1);
-            FA2_BWD(80, 1, 2, 1, 2);
+            if (variant == 1) FA2_BWD(64, 2, 2, 2, 1, true);
+            if (variant == 2) FA2_BWD(64, 2, 2, 1, 2, false);
+            FA2_BWD(64, 2, 2, 1, 2, true);
+        case 80:                                                // one wave per SIMD, 32 rows per wave (measured best)
+            if (variant == 1) FA2_BWD(80, 1, 2, 1, 2, false);
+            if (variant == 2) FA2_BWD(80, 2, 1, 2, 1, true);
+            FA2_BWD(80, 2, 1, 2, 1, false);
         default: return -100;
     }
 #undef FA2_BWD
