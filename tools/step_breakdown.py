@@ -7,9 +7,10 @@ import sys
 
 CLASSES = [
     ("skp Winograd conv3x3", ("skp_wino",)),
-    ("skp flash self-attention", ("skp_self_attn",)),
+    ("skp flash attention (self + long-key cross)", ("skp_self_attn", "skp_fa2_")),
+    ("skp attention map fwd/bwd (north-star kernel)", ("skp_attn_map",)),
     ("skp fused GroupNorm+SiLU / bias+residual", ("skp_group_norm", "skp_gn_", "skp_add_bias")),
-    ("skp map/cross-attn/selection/loss/gemm", ("skp_",)),
+    ("skp cross-attn (T<=128) / selection / loss / small gemm / geglu / layout", ("skp_",)),
     ("conv (MIOpen)", ("igemm", "Igemm", "conv", "Conv", "winograd", "Winograd", "gridwise_convolution", "naive_conv",
                        "SubTensorOpWithScalar", "batched_transpose", "Im2Col", "Col2Im", "kernel_grouped_conv")),
     ("gemm (hipBLASLt/rocBLAS)", ("Cijk", "gemm", "Gemm")),
@@ -58,7 +59,8 @@ def main():
     for cls, ns in sorted(tot.items(), key=lambda kv: -kv[1]):
         print(f"| {cls} | {ns / nwin / 1e6:.2f} | {100 * ns / total:.1f} |")
     print()
-    for cls in ("conv (MIOpen)", "skp Winograd conv3x3", "elementwise / copy (ATen)", "other"):
+    for cls in ("conv (MIOpen)", "skp Winograd conv3x3", "skp flash attention (self + long-key cross)", "elementwise / copy (ATen)",
+                "other"):
         print(f"top kernels in '{cls}':")
         for n, (ns, c) in sorted(names.get(cls, {}).items(), key=lambda kv: -kv[1][0])[:8]:
             print(f"  {ns / nwin / 1e6:7.2f} ms/step  {c / nwin:6.1f} calls/step  {n}")
