@@ -17,6 +17,7 @@
  *   skp_cross_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (ordinary softmax(QK^T)V, cross layers)
  *   skp_self_attn_fwd_f32 / _bwd_f32        ptp_utils.py:493-506,540 (self-attention layers, flash-style)
  *   skp_flash_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (any key count: cross layers with T > 128 tokens)
+ *   skp_conv3x3[_f4]_f32 / skp_conv3x3_s2_f32  3x3 convolutions of the frozen UNet / VAE blocks (ptp_utils.py:227-229, 289-304)
  *   skp_group_norm_fwd_f32 / _bwd_f32       GroupNorm+SiLU of the hooked UNet / VAE forward (ptp_utils.py:227-229, 289-304)
  *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
  *   skp_select_tokens                       ptp_utils.py:110-112,115-159
@@ -186,6 +187,17 @@ int skp_conv3x3_f4_filter_f32(const void* w, void* U, int Cout, int Cin, int fli
 int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int W);
 int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
                        int B, int Cin, int Cout, int H, int W, void* stream);
+
+/* 3x3 / STRIDE 2 convolution, forward (diffusers Downsample2D [third party]: the three down-sampling convolutions of the
+ * frozen VAE encoder, reached from ptp_utils.py:289-304 `image2latent`, run under no_grad), direct implicit GEMM on the fp32
+ * matrix cores, NCHW in and out, zero padding and bias folded in (no F.pad copy, no NCHW<->NHWC transposes):
+ *   y[b,co,oy,ox] = bias[co] + sum_{ci,a,c} w[co,ci,a,c] * x[b,ci,2*oy+a-pad,2*ox+c-pad]   (out of range = 0), OH = H/2, OW = W/2
+ *   pad = 0: the asymmetric (0,1,0,1) padding of the VAE's Downsample2D(padding=0); pad = 1: symmetric padding 1.
+ * skp_conv3x3_s2_filter_f32: one-off re-ordering of a frozen weight w [Cout,Cin,3,3] into U [9][Cin/16][4][Cout][4].
+ * Limits: Cin % 16 == 0, Cout % 32 == 0, H/2 % 8 == 0, W/2 % 16 == 0, x, U, y < 2 GiB each; bias may be NULL. */
+int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int Cin, void* stream);
+int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
+                       int pad, void* stream);
 
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0

@@ -1,0 +1,189 @@
+// 3x3 / stride 2 convolution (forward) as an implicit GEMM on the fp32 matrix cores, NCHW in and out, zero padding and
+// bias folded in: the down-sampling convolutions of the frozen VAE encoder (diffusers Downsample2D with padding 0:
+// F.pad(x, (0,1,0,1)) then conv(stride 2) [third party], reached from ptp_utils.py:289-304 `image2latent`) and the UNet's
+// Downsample2D (padding 1).  On the library path these three VAE layers cost the step 3.7 ms of implicit-GEMM kernels at
+// ~0.5 of the fp32 peak plus 1.5 ms of NCHW<->NHWC transposes plus 1 ms of F.pad copies; Winograd does not apply to
+// stride 2, but a direct form needs no transform arithmetic at all, so nearly every issued instruction is an MFMA.
+//
+//   y[b,co,oy,ox] = bias[co] + sum_{ci,a,c} w[co,ci,a,c] * x[b,ci, 2 oy + a - p, 2 ox + c - p]      (out of range = 0)
+//   p = 0: the asymmetric (0,1,0,1) padding of the VAE;  p = 1: symmetric padding 1.   OH = H/2, OW = W/2.
+//
+// GEMM view: M = Cout, N = output pixels, K = (tap, ci).  v_mfma_f32_16x16x4_f32; k-slot kq = lane >> 4 and MFMA step m
+// contract input channel 4 kq + m of the current 16-channel stage (the operand order of skp_conv_wino4.hip):
+//   A  filter, pre-arranged once per frozen weight as U[tap][ci/16][kq][co][m]  -> one 16-byte load per (tap, 16 channels)
+//   B  input patch in LDS, channel-interleaved [kq][row][col][m]                -> one ds_read_b128 per (tap, 16 pixels)
+// Workgroup = 8 x 16 output pixels x 128 output channels; wave = 32 channels (2 M tiles) x 8 rows of 16 pixels = 16
+// accumulator tiles (64 registers) -> two workgroups per CU.  Per 16-channel stage a wave issues 576 MFMAs for 72 LDS
+// reads and 18 filter loads; the next stage's 17 x 33 x 16 input patch is fetched with 48 buffer_load_dword per thread
+// (position fixed per thread, channel = scalar offset: no address arithmetic in the loop; out-of-range offsets return 0 =
+// the zero padding) while the current stage computes, and goes to the other LDS buffer afterwards (one barrier per stage).
+#include "skp_common.h"
+
+namespace {
+
+constexpr int S2_TOH = 8, S2_TOW = 16;                    // output tile
+constexpr int S2_ROWS = 2 * S2_TOH + 1, S2_COLS = 2 * S2_TOW + 1;   // 17 x 33 input patch
+constexpr int S2_POS = S2_ROWS * S2_COLS;                 // 561 positions per channel
+constexpr int S2_SLOTS = (S2_POS + 255) / 256;            // 3 positions per thread
+constexpr int S2_STAGE = 4 * S2_POS * 4;                  // floats per LDS stage: [kq][pos][m]
+
+__global__ void skp_conv_s2_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    const int c16 = ci >> 4, kq = (ci >> 2) & 3, m = ci & 3, C16 = Cin >> 4;
+    const float* p = w + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) U[((((size_t)tap * C16 + c16) * 4 + kq) * Cout + co) * 4 + m] = p[tap];
+}
+
+struct S2Args {
+    const float* x; const float* U; const float* bias; float* y;
+    int B, Cin, Cout, H, W, OH, OW, pad;
+    int tilesX, tilesPerImg;
+    unsigned x_bytes, u_bytes, y_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [2][4 kq][561 pos][4 m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x, cg = blockIdx.y;
+    const int b = tile / a.tilesPerImg, rem = tile - b * a.tilesPerImg;
+    const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+    const int oy0 = ty * S2_TOH, ox0 = tx * S2_TOW;
+    const int HW = a.H * a.W;
+    const int co0 = cg * 128 + wave * 32;
+    const int nsteps = a.Cin >> 4, C16 = nsteps;
+
+    // ---- staging role: thread -> up to 3 fixed positions of the 17 x 33 patch; the channel is a scalar offset ----
+    int goff[S2_SLOTS], loff[S2_SLOTS];
+#pragma unroll
+    for (int u = 0; u < S2_SLOTS; ++u) {
+        const int pos = tid + 256 * u;
+        const int row = pos / S2_COLS, col = pos - row * S2_COLS;
+        const int iy = 2 * oy0 + row - a.pad, ix = 2 * ox0 + col - a.pad;
+        const bool ok = pos < S2_POS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        goff[u] = ok ? ((b * a.Cin) * HW + iy * a.W + ix) * 4 : SKP_OOB;
+        loff[u] = pos < S2_POS ? pos * 4 : -1;
+    }
+    const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
+    const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
+    float pre[S2_SLOTS][16];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < S2_SLOTS; ++u)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pre[u][c] = skp_buf_load_f32(xrs, goff[u], (s * 16 + c) * HW * 4, 0);
+    };
+    auto put = [&](int buf) {
+        float* dst = xs + buf * S2_STAGE;
+#pragma unroll
+        for (int u = 0; u < S2_SLOTS; ++u)
+            if (loff[u] >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *(f32x4*)(dst + q * (S2_POS * 4) + loff[u]) = f32x4{pre[u][4 * q], pre[u][4 * q + 1], pre[u][4 * q + 2], pre[u][4 * q + 3]};
+            }
+    };
+
+    f32x4 acc[2][S2_TOH];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < S2_TOH; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // filter operand offsets: U[tap][c16][kq][co][m]
+    int uvo[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) uvo[mt] = (kq * a.Cout + min(co0 + 16 * mt + i16, a.Cout - 1)) * 16;
+    const int u_c16 = 4 * a.Cout * 16, u_tap = C16 * u_c16;
+
+    fetch(0);
+    put(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) fetch(s + 1);
+        const float* xb = xs + (s & 1) * S2_STAGE + kq * (S2_POS * 4);
+        f32x4 ua[3][2];                                           // filter ring, two taps ahead
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) ua[t][mt] = skp_buf_load_f32x4(urs, uvo[mt], t * u_tap + s * u_c16, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) ua[(tap + 2) % 3][mt] = skp_buf_load_f32x4(urs, uvo[mt], (tap + 2) * u_tap + s * u_c16, 0);
+            }
+            const int ta = tap / 3, tc = tap - 3 * ta;
+            f32x4 bv[S2_TOH];
+#pragma unroll
+            for (int nt = 0; nt < S2_TOH; ++nt) bv[nt] = *(const f32x4*)(xb + ((2 * nt + ta) * S2_COLS + 2 * i16 + tc) * 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)                         // an accumulator is revisited after 15 other MFMAs
+#pragma unroll                                                   // (dependent-issue latency of 16x16x4 is 40 cycles > its 32-cycle issue)
+                for (int nt = 0; nt < S2_TOH; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[tap % 3][mt][m], bv[nt][m], acc[mt][nt], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) put((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = pixel (16 consecutive ox of row oy0 + nt), registers = 4 output channels ----
+    const i32x4 yrs = skp_make_rsrc(a.y, a.y_bytes);
+    const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 16 * mt + 4 * kq + r;
+            const bool cok = co < a.Cout;
+            const float bv = skp_buf_load_f32(brs, cok ? co * 4 : SKP_OOB, 0, 0);
+            const int base = ((b * a.Cout + co) * a.OH + oy0) * a.OW + ox0 + i16;
+#pragma unroll
+            for (int nt = 0; nt < S2_TOH; ++nt)
+                skp_buf_store_f32(acc[mt][nt][r] + bv, yrs, cok ? (base + nt * a.OW) * 4 : SKP_OOB, 0, 0);
+        }
+}
+
+}  // namespace
+
+extern "C" int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int Cin, void* stream) {
+    if (!w || !U || Cout <= 0 || Cin <= 0) return SKP_E_BADARG;
+    if (Cin & 15) return SKP_E_RANGE;
+    const int n = Cout * Cin;
+    hipLaunchKernelGGL(skp_conv_s2_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w,
+                       (float*)U, Cout, Cin);
+    return skp_launch_status();
+}
+
+extern "C" int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H,
+                                  int W, int pad, void* stream) {
+    if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (pad != 0 && pad != 1)) return SKP_E_BADARG;
+    if ((Cin & 15) || (Cout & 31) || (H & 1) || (W & 1)) return SKP_E_RANGE;
+    const int OH = H / 2, OW = W / 2;
+    if ((OH % S2_TOH) || (OW % S2_TOW)) return SKP_E_RANGE;
+    const unsigned long long xb = (unsigned long long)B * Cin * H * W * 4, ub = (unsigned long long)9 * Cin * Cout * 4,
+                             yb = (unsigned long long)B * Cout * OH * OW * 4;
+    if (xb >= 0x80000000ull || ub >= 0x80000000ull || yb >= 0x80000000ull) return SKP_E_RANGE;
+    S2Args a;
+    a.x = (const float*)x; a.U = (const float*)U; a.bias = (const float*)bias; a.y = (float*)y;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.pad = pad;
+    a.tilesX = OW / S2_TOW;
+    a.tilesPerImg = a.tilesX * (OH / S2_TOH);
+    a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
+    const long tiles = (long)B * a.tilesPerImg;
+    if (tiles > 0x7fffffffL) return SKP_E_RANGE;
+    const size_t lds = (size_t)2 * S2_STAGE * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)skp_conv_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(skp_conv_s2_kernel, dim3((unsigned)tiles, (Cout + 127) / 128), dim3(256), lds, (hipStream_t)stream, a);
+    return skp_launch_status();
+}

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .attention import AttentionBlock, Transformer2DModel
-from .unet import ResnetBlock2D
+from .unet import Downsample2D, ResnetBlock2D
 
 
 def _resnet_forward(m: ResnetBlock2D):
@@ -65,9 +65,26 @@ def _conv_forward(m: torch.nn.Conv2d):
     return forward
 
 
+def _downsample_forward(m):
+    """Downsample2D: where no gradient is needed (the VAE encoder runs under no_grad) the stride-2 convolution, its zero
+    padding and its bias are one kernel (csrc/skp_conv_s2.hip); otherwise the module's own forward (library)."""
+    orig = m.forward
+
+    def forward(x):
+        needs_grad = torch.is_grad_enabled() and x.requires_grad
+        if (not needs_grad and not m.conv.weight.requires_grad and m.conv.stride == (2, 2)
+                and ops.conv3x3_s2_supported(x, m.conv.weight)):
+            return ops.conv3x3_s2(x, m.conv.weight, m.conv.bias, pad=0 if m.padding == 0 else 1)
+        return orig(x)
+    return forward
+
+
 def fuse_norms(module: torch.nn.Module) -> int:
     n = 0
     for mod in module.modules():
+        if isinstance(mod, Downsample2D) and "forward" not in mod.__dict__:
+            mod.forward = _downsample_forward(mod); n += 1
+            continue
         if (isinstance(mod, torch.nn.Conv2d) and mod.kernel_size == (3, 3) and mod.stride == (1, 1)
                 and mod.padding == (1, 1) and mod.dilation == (1, 1) and mod.groups == 1
                 and mod.padding_mode == "zeros" and "forward" not in mod.__dict__):

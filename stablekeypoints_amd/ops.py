@@ -627,6 +627,43 @@ def conv3x3_auto(x, weight, bias=None, residual=None):
     return (y + bias[None, :, None, None] if bias is not None else y) + residual
 
 
+# ---------------------------------------------------------------------------------------------------------
+# 3x3 / stride 2 down-sampling convolutions of the frozen VAE encoder (forward only: they run under no_grad).
+# ---------------------------------------------------------------------------------------------------------
+def conv3x3_s2_supported(x, weight) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    b, ci, h, w = (int(v) for v in x.shape)
+    co = int(weight.shape[0])
+    return (CONV3X3_MODE != "lib" and int(weight.shape[1]) == ci and ci % 16 == 0 and co % 32 == 0 and h % 16 == 0
+            and w % 32 == 0 and max(b * ci * h * w, b * co * (h // 2) * (w // 2), 9 * ci * co) * 4 < 2 ** 31)
+
+
+def conv3x3_s2(x, weight, bias=None, pad: int = 0):
+    """y = conv2d(zero-extended x, weight, bias, stride 2): pad = 0 is F.pad(x, (0,1,0,1)) + padding 0 (the VAE's
+    Downsample2D), pad = 1 is padding 1.  No autograd: frozen weights and an input that needs no gradient."""
+    x = _dev(x.detach(), "x")
+    if weight.requires_grad or torch.is_grad_enabled() and x.requires_grad:
+        raise RuntimeError("conv3x3_s2 is forward-only")
+    key = "_skp_s2"
+    hit = getattr(weight, key, None)
+    tag = (weight._version, weight.data_ptr())
+    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
+        U = hit[1]
+    else:
+        w = _dev(weight.detach(), "weight")
+        U = torch.empty(9 * w.shape[0] * w.shape[1], device=w.device, dtype=torch.float32)
+        N.check(N.lib().skp_conv3x3_s2_filter_f32(w.data_ptr(), U.data_ptr(), w.shape[0], w.shape[1], _stream()),
+                "skp_conv3x3_s2_filter_f32")
+        setattr(weight, key, (tag, U))
+    B, ci, H, W = x.shape
+    co = weight.shape[0]
+    y = torch.empty(B, co, H // 2, W // 2, device=x.device, dtype=torch.float32)
+    N.check(N.lib().skp_conv3x3_s2_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                       B, ci, co, H, W, int(pad), _stream()), "skp_conv3x3_s2_f32")
+    return y
+
+
 class GEGLUFn(torch.autograd.Function):
     """h * gelu(gate) on the feed-forward projection [.., 2*inner] (h = first half, gate = second half)."""
 

@@ -407,3 +407,42 @@ def test_sd21_sdxl_full_width_trees_one_forward(ops):
         assert torch.isfinite(ctx.grad).all() and ctx.grad.abs().max().item() > 0
         del ldm, controllers, controller, recs, M
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,pad,bias", [(2, 32, 32, 32, 64, 0, True), (1, 48, 96, 16, 32, 1, False), (2, 128, 128, 64, 64, 0, True),
+                                                  (1, 320, 320, 32, 32, 1, True), (3, 16, 64, 48, 96, 0, True)])
+def test_stride2_conv_vs_fp64(ops, B, ci, co, H, W, pad, bias):
+    """The direct fp32-MFMA 3x3 / stride-2 convolution (diffusers Downsample2D: pad 0 = F.pad(x,(0,1,0,1)) + padding 0 as in
+    the VAE encoder, pad 1 = padding 1 as in the UNet) against fp64; ragged channel groups (Cout = 96, 320) included."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, generator=g) if bias else None
+    xd = x.double()
+    if pad == 0:
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xd, (0, 1, 0, 1)), w.double(), None if b is None else b.double(), stride=2)
+    else:
+        ref = torch.nn.functional.conv2d(xd, w.double(), None if b is None else b.double(), stride=2, padding=1)
+    xg, wg = x.cuda(), w.cuda()
+    assert ops.conv3x3_s2_supported(xg, wg)
+    with torch.no_grad():
+        y = ops.conv3x3_s2(xg, wg, None if b is None else b.cuda(), pad=pad)
+        y2 = ops.conv3x3_s2(xg, wg, None if b is None else b.cuda(), pad=pad)
+    assert y.shape == ref.shape
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-4, atol=2e-5 * ref.abs().max().item())
+    assert torch.equal(y, y2)                                   # deterministic
+    # the module route: Downsample2D under no_grad takes the kernel, with grad it keeps the library path
+    from stablekeypoints_amd.ldm.unet import Downsample2D
+    from stablekeypoints_amd.ldm.fused import fuse_norms
+    if ci == co:
+        m = Downsample2D(ci, padding=pad).cuda()
+        for p_ in m.parameters():
+            p_.requires_grad = False
+        with torch.no_grad():
+            lib = m(xg)
+            assert fuse_norms(m) == 1
+            mine = m(xg)
+        torch.testing.assert_close(mine, lib, rtol=1e-4, atol=2e-5 * lib.abs().max().item())
+        xr = xg.clone().requires_grad_(True)
+        m(xr).sum().backward()                                  # gradient needed -> library path, still differentiable
+        assert xr.grad is not None
