@@ -6,7 +6,7 @@ import csv
 import sys
 
 CLASSES = [
-    ("skp Winograd conv3x3", ("skp_wino",)),
+    ("skp conv3x3 (Winograd stride 1 + direct stride 2)", ("skp_wino", "skp_conv_s2")),
     ("skp flash attention (self + long-key cross)", ("skp_self_attn", "skp_fa2_")),
     ("skp attention map fwd/bwd (north-star kernel)", ("skp_attn_map",)),
     ("skp fused GroupNorm+SiLU / bias+residual", ("skp_group_norm", "skp_gn_", "skp_add_bias")),
@@ -59,7 +59,7 @@ def main():
     for cls, ns in sorted(tot.items(), key=lambda kv: -kv[1]):
         print(f"| {cls} | {ns / nwin / 1e6:.2f} | {100 * ns / total:.1f} |")
     print()
-    for cls in ("conv (MIOpen)", "skp Winograd conv3x3", "skp flash attention (self + long-key cross)", "elementwise / copy (ATen)",
+    for cls in ("conv (MIOpen)", "skp conv3x3 (Winograd stride 1 + direct stride 2)", "skp flash attention (self + long-key cross)", "elementwise / copy (ATen)",
                 "other"):
         print(f"top kernels in '{cls}':")
         for n, (ns, c) in sorted(names.get(cls, {}).items(), key=lambda kv: -kv[1][0])[:8]:
