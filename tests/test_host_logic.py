@@ -203,3 +203,80 @@ def test_conv3x3_shape_rules():
     assert not ops.conv3x3_f4_ok((8, 320, 66, 64), (320, 320, 3, 3))            # H % 4 != 0 -> F(2x2,3x3)
     assert ops.conv3x3_wanted((8, 320, 66, 64), (320, 320, 3, 3)) == (ops.CONV3X3_MODE != "lib")
     assert not ops.conv3x3_wanted((1, 32, 4, 4), (32, 32, 3, 3))               # too few tiles -> library
+
+
+def test_checkpoint_directory_loading_is_strict(tmp_path):
+    """`load_ldm(<dir>)`: both accepted layouts load key by key; a missing / mismatched / unexpected key raises (only the VAE
+    decoder half is tolerated); a hub id that is not a local directory raises instead of silently building random weights."""
+    import json
+    from safetensors.torch import save_file
+    from stablekeypoints_amd.ldm.pipeline import ARCHS, StableDiffusionPipeline
+    from stablekeypoints_amd.optimize_token import load_ldm
+    unet, vae = StableDiffusionPipeline.build("tiny-sdxl", seed=7)
+    # (a) diffusers layout: <dir>/unet/{config.json, diffusion_pytorch_model.safetensors}, <dir>/vae/... (+ decoder keys)
+    d = tmp_path / "some-xl-checkpoint"
+    (d / "unet").mkdir(parents=True); (d / "vae").mkdir()
+    cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in ARCHS["tiny-sdxl"]["unet"].items()}
+    (d / "unet" / "config.json").write_text(json.dumps(cfg))
+    save_file({k: v.contiguous() for k, v in unet.state_dict().items()}, str(d / "unet" / "diffusion_pytorch_model.safetensors"))
+    vsd = {k: v.contiguous() for k, v in vae.state_dict().items()}
+    # the real VAE tree of this topology is wider than the sd15-shaped default: store it as .bin with decoder leftovers
+    vsd["decoder.conv_in.weight"] = torch.zeros(4, 4, 3, 3)
+    vsd["post_quant_conv.weight"] = torch.zeros(4, 4, 1, 1)
+    torch.save(vsd, str(d / "vae" / "diffusion_pytorch_model.bin"))
+    # the VAE of `tiny-sdxl` is reduced-width; the loader builds the VAE of the guessed arch ("xl" in the name -> sdxl, full width)
+    with pytest.raises(RuntimeError, match="shape mismatches"):
+        load_ldm("cpu", str(d), feature_upsample_res=32)
+    # (b) flat layout with matching trees: unet.pt / vae.pt of the tiny model under a tiny-named directory
+    d2 = tmp_path / "tiny-sdxl"
+    d2.mkdir()
+    torch.save(unet.state_dict(), str(d2 / "unet.pt"))
+    torch.save(vae.state_dict(), str(d2 / "vae.pt"))
+    import stablekeypoints_amd.ldm.pipeline as P
+    orig = P.guess_arch
+    P.guess_arch = lambda name: "tiny-sdxl"
+    try:
+        ldm, _, _ = load_ldm("cpu", str(d), feature_upsample_res=32)          # diffusers layout, decoder keys tolerated
+        assert not ldm.synthetic_weights and ldm.unet.config["cross_attention_dim"] == 128
+        assert torch.equal(ldm.vae.encoder.conv_in.weight, vae.encoder.conv_in.weight)
+        ldm, _, _ = load_ldm("cpu", str(d2), feature_upsample_res=32)
+        assert not ldm.synthetic_weights
+        for (k, a_), (_, b_) in zip(ldm.unet.state_dict().items(), unet.state_dict().items()):
+            assert torch.equal(a_, b_), k
+        sd = unet.state_dict(); sd.pop("conv_in.bias")
+        torch.save(sd, str(d2 / "unet.pt"))
+        with pytest.raises(RuntimeError, match="1 missing"):
+            load_ldm("cpu", str(d2), feature_upsample_res=32)
+        sd = unet.state_dict(); sd["surprise.weight"] = torch.zeros(1)
+        torch.save(sd, str(d2 / "unet.pt"))
+        with pytest.raises(RuntimeError, match="1 unexpected"):
+            load_ldm("cpu", str(d2), feature_upsample_res=32)
+    finally:
+        P.guess_arch = orig
+    with pytest.raises(FileNotFoundError, match="not a local checkpoint directory"):
+        load_ldm("cpu", "sd-legacy/stable-diffusion-v1-5", feature_upsample_res=32)
+
+
+def test_sd2x_sdxl_module_tree_contract():
+    """Published parameter counts of the SD-2.1 and SDXL-base UNets, hooked-layer census, embedding width."""
+    from stablekeypoints_amd.ldm.pipeline import ARCHS
+    from stablekeypoints_amd.ldm.unet import UNet2DConditionModel
+    from stablekeypoints_amd import ptp_utils
+    with torch.device("meta"):
+        sd21 = UNet2DConditionModel(**ARCHS["sd21"]["unet"])
+        sdxl = UNet2DConditionModel(**ARCHS["sdxl"]["unet"])
+    assert sum(p.numel() for p in sd21.parameters()) == 865_910_724
+    assert sum(p.numel() for p in sdxl.parameters()) == 2_567_463_684
+    k21, kxl = dict(sd21.state_dict()), dict(sdxl.state_dict())
+    assert tuple(k21["up_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight"].shape) == (1280, 1024)
+    assert tuple(k21["up_blocks.1.attentions.0.proj_in.weight"].shape) == (1280, 1280)          # linear projection
+    assert tuple(kxl["up_blocks.0.attentions.0.transformer_blocks.9.attn2.to_k.weight"].shape) == (1280, 2048)
+    assert tuple(kxl["add_embedding.linear_1.weight"].shape) == (1280, 2816)
+    assert "down_blocks.0.attentions.0.norm.weight" not in kxl                                    # SDXL starts with a DownBlock2D
+    for net, n_up in ((sd21, 18), (sdxl, 2 * (3 * 10 + 3 * 2))):
+        c = ptp_utils.AttentionStore()
+        ptp_utils.register_attention_control(net, c, feature_upsample_res=128)
+        assert c.num_att_layers == n_up
+    heads = {m.heads for n, m in sdxl.named_modules() if m.__class__.__name__ == "CrossAttention"}
+    assert heads == {10, 20}
+    assert tuple(ptp_utils.init_random_noise("cpu", 77, sdxl.config["cross_attention_dim"]).shape) == (1, 77, 2048)

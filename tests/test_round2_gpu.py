@@ -446,3 +446,21 @@ def test_stride2_conv_vs_fp64(ops, B, ci, co, H, W, pad, bias):
         xr = xg.clone().requires_grad_(True)
         m(xr).sum().backward()                                  # gradient needed -> library path, still differentiable
         assert xr.grad is not None
+
+
+@pytest.mark.parametrize("arch", ["tiny-sd21", "tiny-sdxl"])
+def test_optimize_embedding_runs_on_sd2x_sdxl_trees(arch):
+    """The reference entry point (`optimize_embedding`, optimize.py:269-452) end to end on the SD-2.x / SDXL-shaped trees:
+    embedding of the architecture's width, finite, changed by the optimisation, loss finite."""
+    from stablekeypoints_amd.optimize import default_args, optimize_embedding
+    from stablekeypoints_amd.optimize_token import load_ldm
+    ldm, controllers, n = load_ldm("cuda", arch, feature_upsample_res=32)
+    width = ldm.unet.config["cross_attention_dim"]
+    args = default_args(num_tokens=24, feature_upsample_res=32, furthest_point_num_samples=10, top_k=4, batch_size=2,
+                        num_steps=4, image_size=128, max_len=4, device="cuda", log_interval=0)
+    ctx0 = torch.randn(1, 24, width, generator=torch.Generator().manual_seed(3))
+    out = optimize_embedding(ldm, args, controllers, n, context=ctx0.clone())
+    assert out.shape == (1, 24, width) and torch.isfinite(out).all() and not out.requires_grad
+    assert (out.cpu() - ctx0).abs().max().item() > 1e-4
+    out2 = optimize_embedding(ldm, args, controllers, n)            # default init follows the architecture's width
+    assert out2.shape == (1, 24, width)
