@@ -188,6 +188,26 @@ int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int W);
 int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
                        int B, int Cin, int Cout, int H, int W, void* stream);
 
+/* Output statistics for the GroupNorm that follows a convolution (diffusers ResnetBlock2D: conv1 -> norm2, conv2 + shortcut
+ * -> the next block's norm1 [third party]): the convolution epilogues leave per-(image, channel, pixel-block) sums of their
+ * OUTPUT (after bias / shortcut) behind, and the norm takes its mean / variance from them instead of re-reading the
+ * activation (one full HBM pass per norm, 1 GB at the VAE's 512^2 level).
+ *   skp_conv3x3_f4_stats_blocks  -> blocks per image (16 tiles = 256 pixels each) for this launch shape, 0 = not available
+ *                                   (split-K launch, or blocks would straddle images)
+ *   skp_conv3x3_f4_stats_f32     = skp_conv3x3_f4_f32 (unsplit) + stats [B][Cout][blocks][2] = {sum y, sum y^2}
+ *   skp_conv3x3_s2_stats_f32     = skp_conv3x3_s2_f32 + stats [B][Cout][(H/16)*(W/32)][2] over 8x16-pixel output tiles
+ *   skp_group_norm_fwd_blocks_f32 = skp_group_norm_fwd_f32 with mean / rstd computed from bs [N][C][nblk][2] (each block =
+ *                                   `pix` pixels, nblk * pix == HW; fp64 combine; the per-(sample, channel) offset is folded in
+ *                                   analytically).  mean, rstd [N,G] are written as usual. */
+int skp_conv3x3_f4_stats_blocks(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4_stats_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, float* stats,
+                             int B, int Cin, int Cout, int H, int W, void* stream);
+int skp_conv3x3_s2_stats_f32(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin, int Cout,
+                             int H, int W, int pad, void* stream);
+int skp_group_norm_fwd_blocks_f32(const float* x, const float* off, const float* gamma, const float* beta, float* y,
+                                  float* mean, float* rstd, const float* bs, int nblk, int pix, int N, int C, int G, int HW,
+                                  float eps, int silu, void* stream);
+
 /* 3x3 / STRIDE 2 convolution, forward (diffusers Downsample2D [third party]: the three down-sampling convolutions of the
  * frozen VAE encoder, reached from ptp_utils.py:289-304 `image2latent`, run under no_grad), direct implicit GEMM on the fp32
  * matrix cores, NCHW in and out, zero padding and bias folded in (no F.pad copy, no NCHW<->NHWC transposes):

@@ -42,6 +42,7 @@ struct S2Args {
     int B, Cin, Cout, H, W, OH, OW, pad;
     int tilesX, tilesPerImg;
     unsigned x_bytes, u_bytes, y_bytes;
+    float* stats;            // optional [B][Cout][tilesPerImg][2] = {sum y, sum y^2} per 8x16-pixel tile (next GroupNorm), or null
 };
 
 __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
@@ -143,9 +144,21 @@ __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
             const bool cok = co < a.Cout;
             const float bv = skp_buf_load_f32(brs, cok ? co * 4 : SKP_OOB, 0, 0);
             const int base = ((b * a.Cout + co) * a.OH + oy0) * a.OW + ox0 + i16;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < S2_TOH; ++nt)
-                skp_buf_store_f32(acc[mt][nt][r] + bv, yrs, cok ? (base + nt * a.OW) * 4 : SKP_OOB, 0, 0);
+            for (int nt = 0; nt < S2_TOH; ++nt) {
+                const float v = acc[mt][nt][r] + bv;
+                skp_buf_store_f32(v, yrs, cok ? (base + nt * a.OW) * 4 : SKP_OOB, 0, 0);
+                s1 += v; s2 += v * v;
+            }
+            if (a.stats) {                                       // uniform branch: tile sums over the 16 pixel lanes
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (i16 == 0 && cok) {
+                    float* dst = a.stats + (((size_t)b * a.Cout + co) * a.tilesPerImg + rem) * 2;
+                    dst[0] = s1; dst[1] = s2;
+                }
+            }
         }
 }
 
@@ -160,8 +173,23 @@ extern "C" int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int C
     return skp_launch_status();
 }
 
+static int s2_run(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin, int Cout, int H, int W,
+                  int pad, void* stream);
+
 extern "C" int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H,
                                   int W, int pad, void* stream) {
+    return s2_run(x, U, bias, y, nullptr, B, Cin, Cout, H, W, pad, stream);
+}
+
+// as above + stats [B][Cout][(H/16)*(W/32)][2]: {sum, sum of squares} of y over each 8x16-pixel output tile
+extern "C" int skp_conv3x3_s2_stats_f32(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin,
+                                        int Cout, int H, int W, int pad, void* stream) {
+    if (!stats) return SKP_E_BADARG;
+    return s2_run(x, U, bias, y, stats, B, Cin, Cout, H, W, pad, stream);
+}
+
+static int s2_run(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin, int Cout, int H, int W,
+                  int pad, void* stream) {
     if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (pad != 0 && pad != 1)) return SKP_E_BADARG;
     if ((Cin & 15) || (Cout & 31) || (H & 1) || (W & 1)) return SKP_E_RANGE;
     const int OH = H / 2, OW = W / 2;
@@ -175,6 +203,7 @@ extern "C" int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias
     a.tilesX = OW / S2_TOW;
     a.tilesPerImg = a.tilesX * (OH / S2_TOH);
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
+    a.stats = stats;
     const long tiles = (long)B * a.tilesPerImg;
     if (tiles > 0x7fffffffL) return SKP_E_RANGE;
     const size_t lds = (size_t)2 * S2_STAGE * sizeof(float);

@@ -78,7 +78,30 @@ struct Wino4Args {
     int ntb, ncg, tb_per_xcd;   // tile blocks, channel groups, tile blocks per XCD band (0: unit-grouped order)
     int splits;                 // K splits
     size_t y_split_stride;
+    float* stats;               // optional [B][Cout][tilesPerImg/16][2] = {sum y, sum y^2} per 16-tile block (next GroupNorm), or null
+    int sblk;                   // 16-tile blocks per image
 };
+
+// Block statistics without register pressure: every lane parks the sum / sum of squares of its 4x4 outputs in the (idle)
+// LDS stage buffers, [slot][64 lanes] float2; after the epilogue 128 threads add the 16 tile lanes of one (channel, block)
+// each in fixed order and store {sum y, sum y^2}.
+__device__ __forceinline__ void w4_park_stats(f32x2* sbuf, int slot, int lane, const f32x4 (&o)[4], bool ok) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int oy = 0; oy < 4; ++oy)
+#pragma unroll
+        for (int ox = 0; ox < 4; ++ox) { s1 += o[oy][ox]; s2 += o[oy][ox] * o[oy][ox]; }
+    sbuf[slot * 64 + lane] = ok ? f32x2{s1, s2} : f32x2{0.f, 0.f};
+}
+__device__ __forceinline__ void w4_store_stats(const Wino4Args& a, const f32x2* sbuf, int slot, int kq, int tile_first, int co) {
+    f32x2 t = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sbuf[slot * 64 + kq * 16 + i];
+    if (co < a.Cout && tile_first < a.nTiles) {
+        const int b = tile_first / a.tilesPerImg, blk = (tile_first - b * a.tilesPerImg) >> 4;
+        *(f32x2*)(a.stats + (((size_t)b * a.Cout + co) * a.sblk + blk) * 2) = t;
+    }
+}
 
 // Workgroup id -> (tile block, channel group, K split).  Ids are dealt round-robin to the 8 XCDs (each with its own
 // L2), so the order decides what the co-resident workgroups of an XCD share:
@@ -128,6 +151,7 @@ __device__ __forceinline__ void w4_out1d(const float (&m)[6], float (&y)[4]) {
     y[3] = d12 + 8.f * d34 + m[5];
 }
 
+template <bool STATS>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
         __syncthreads();
     }
     run_stage(nsteps - 1, std::integral_constant<int, 1>{});
+    if (STATS) __syncthreads();                      // the epilogue parks statistics in the stage buffers
 
     // ---- output transform (in-lane) + store.  Branch-free: invalid tiles/channels store out of range (dropped). ----
     const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
@@ -328,7 +353,15 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
             }
 #pragma unroll
             for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            if (STATS) w4_park_stats((f32x2*)vst, wave * 8 + r * 2 + tb, lane, rr[r][tb], ok);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (STATS) {                                     // 64 channels x 2 tile blocks = 128 (channel, block) pairs
+        __syncthreads();
+        if (tid < 128) {
+            const int wv = tid >> 5, tb = (tid >> 4) & 1, lc = tid & 15;
+            w4_store_stats(a, (const f32x2*)vst, wv * 8 + (lc & 3) * 2 + tb, lc >> 2, tile0 + tb * 16, (cg * 4 + wv) * 16 + lc);
         }
     }
 }
@@ -339,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
 // two), at the price of two filter operand loads per position instead of one.  LDS stage: [36][4][16] f32x4 = 36 KB.
 constexpr int W4C_STAGE_F4 = 36 * 4 * 16;
 constexpr int W4C_RING = 6;                      // ring slots per channel block (divides 36)
+template <bool STATS>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -472,6 +506,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         __syncthreads();
     }
     run_stage(nsteps - 1, std::integral_constant<int, 1>{});
+    if (STATS) __syncthreads();                      // the epilogue parks statistics in the stage buffers
 
     const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
@@ -521,7 +556,15 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         }
 #pragma unroll
         for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[e][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+        if (STATS) w4_park_stats((f32x2*)vst, wave * 8 + e, lane, rr[e], ok);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (STATS) {                                     // 128 channels of one tile block
+        __syncthreads();
+        if (tid < 128) {
+            const int wv = tid >> 5, lc = tid & 31;
+            w4_store_stats(a, (const f32x2*)vst, wv * 8 + ((lc >> 4) << 2) + (lc & 3), (lc >> 2) & 3, tile0, (cg * 4 + wv) * 32 + lc);
+        }
     }
 }
 
@@ -576,8 +619,31 @@ extern "C" int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int
     return S > 1 ? (int64_t)S * B * Cout * H * W * (int64_t)sizeof(float) : 0;
 }
 
+// 16-tile blocks per image when the kernels can emit output statistics for this launch (unsplit, blocks do not straddle
+// images), else 0
+extern "C" int skp_conv3x3_f4_stats_blocks(int B, int Cin, int Cout, int H, int W) {
+    const int S = wino4_plan(B, Cin, Cout, H, W);
+    if (S != 1) return 0;
+    const int tpi = (H / 4) * (W / 4);
+    return (tpi % 32 == 0) ? tpi / 16 : 0;          // 32: the 64-channel form walks two 16-tile blocks per workgroup
+}
+
+static int wino4_run(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace, float* stats,
+                     int B, int Cin, int Cout, int H, int W, void* stream);
+
 extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y,
                                   void* workspace, int B, int Cin, int Cout, int H, int W, void* stream) {
+    return wino4_run(x, U, bias, residual, y, workspace, nullptr, B, Cin, Cout, H, W, stream);
+}
+
+extern "C" int skp_conv3x3_f4_stats_f32(const void* x, const void* U, const void* bias, const void* residual, void* y,
+                                        float* stats, int B, int Cin, int Cout, int H, int W, void* stream) {
+    if (!stats || skp_conv3x3_f4_stats_blocks(B, Cin, Cout, H, W) == 0) return SKP_E_RANGE;
+    return wino4_run(x, U, bias, residual, y, nullptr, stats, B, Cin, Cout, H, W, stream);
+}
+
+static int wino4_run(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace, float* stats,
+                     int B, int Cin, int Cout, int H, int W, void* stream) {
     if (!x || !U || !y) return SKP_E_BADARG;
     int S = wino4_plan(B, Cin, Cout, H, W);
     if (S == 0) return (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) ? SKP_E_BADARG : SKP_E_RANGE;
@@ -599,13 +665,19 @@ extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias
     a.y = S > 1 ? (float*)workspace : (float*)y;
     a.bias = S > 1 ? nullptr : (const float*)bias;
     a.res = S > 1 ? nullptr : (const float*)residual;
+    a.stats = S > 1 ? nullptr : stats;
+    a.sblk = a.tilesPerImg / 16;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4), lds_c = (size_t)2 * W4C_STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_wino4_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino4_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        e = hipFuncSetAttribute((const void*)skp_wino4_conv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -617,13 +689,15 @@ extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias
         a.ncg = Cout / 128;
         a.tb_per_xcd = a.ntb >= 64 ? (a.ntb + 7) / 8 : 0;
         dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
-        hipLaunchKernelGGL(skp_wino4_conv_c128_kernel, grid, dim3(256), lds_c, st, a);
+        if (a.stats) hipLaunchKernelGGL(skp_wino4_conv_c128_kernel<true>, grid, dim3(256), lds_c, st, a);
+        else hipLaunchKernelGGL(skp_wino4_conv_c128_kernel<false>, grid, dim3(256), lds_c, st, a);
     } else {                                        // 64 channels x 32 tiles per workgroup
         a.ntb = (a.nTiles + 31) / 32;
         a.ncg = (Cout + 63) / 64;
         a.tb_per_xcd = a.ntb >= 32 ? (a.ntb + 7) / 8 : 0;
         dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
-        hipLaunchKernelGGL(skp_wino4_conv_kernel, grid, dim3(256), lds, st, a);
+        if (a.stats) hipLaunchKernelGGL(skp_wino4_conv_kernel<true>, grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(skp_wino4_conv_kernel<false>, grid, dim3(256), lds, st, a);
     }
     int rc = skp_launch_status();
     if (rc || S == 1) return rc;

@@ -61,14 +61,50 @@ __device__ __forceinline__ void skp_gn_finalize(const float* partial, int row, i
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// Statistics from the block sums a producing convolution left behind (skp_conv3x3_f4_stats_f32 / skp_conv3x3_s2_stats_f32):
+// bs[n][c][blk] = {sum y, sum y^2} over `pix` pixels each.  One workgroup per (sample, group); fp64 combine; the
+// per-(sample, channel) offset is folded in analytically: sum (y+o) = s + cnt o, sum (y+o)^2 = q + 2 o s + cnt o^2.
+__global__ __launch_bounds__(256) void skp_gn_from_blocks_kernel(GNArgs a, const float* __restrict__ bs, int nblk, int pix,
+                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = tid; e < Cg * nblk; e += 256) {
+        const int cl = e / nblk, blk = e - cl * nblk, c = g * Cg + cl;
+        const float* p = bs + (((size_t)n * a.C + c) * nblk + blk) * 2;
+        const double o = a.off ? (double)a.off[(size_t)n * a.C + c] : 0.0;
+        const double s = p[0], q = p[1];
+        s1 += s + pix * o;
+        s2 += q + 2.0 * o * s + pix * o * o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        const double t1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), t2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double m = t1 / (double)a.L;
+        double var = t2 / (double)a.L - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        mean_out[row] = (float)m;
+        rstd_out[row] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+}
+
+// partial == nullptr: mean / rstd were produced by skp_gn_from_blocks_kernel (read, not written)
 __global__ __launch_bounds__(256) void skp_gn_apply_kernel(GNArgs a, const float* __restrict__ partial,
                                                            float* __restrict__ y, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out) {
     const int row = blockIdx.y, tid = threadIdx.x;
     const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
     float mean, rstd;
-    skp_gn_finalize(partial, row, a.nsplit, a.L, a.eps, mean, rstd);
-    if (blockIdx.x == 0 && tid == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    if (partial) {
+        skp_gn_finalize(partial, row, a.nsplit, a.L, a.eps, mean, rstd);
+        if (blockIdx.x == 0 && tid == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    } else {
+        mean = mean_out[row]; rstd = rstd_out[row];
+    }
     const float* xr = a.x + (size_t)row * a.L;
     float* yr = y + (size_t)row * a.L;
     const int hw4 = a.HW / 4;
@@ -211,6 +247,28 @@ extern "C" int skp_group_norm_fwd_f32(const float* x, const float* off, const fl
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(skp_gn_apply_kernel, dim3((unsigned)blocks, N * G), dim3(256), 0, st, a,
                        (const float*)workspace, y, mean, rstd);
+    return skp_launch_status();
+}
+
+// Forward with the statistics taken from a producer's block sums instead of a pass over x:
+// bs [N][C][nblk][2], every block covering `pix` pixels (nblk * pix == HW).
+extern "C" int skp_group_norm_fwd_blocks_f32(const float* x, const float* off, const float* gamma, const float* beta,
+                                             float* y, float* mean, float* rstd, const float* bs, int nblk, int pix, int N, int C,
+                                             int G, int HW, float eps, int silu, void* stream) {
+    GNArgs a{};
+    int rc = gn_fill(a, x, off, gamma, beta, N, C, G, HW, eps, silu);
+    if (rc) return rc;
+    if (!y || !mean || !rstd || !bs || nblk <= 0 || pix <= 0) return SKP_E_BADARG;
+    if ((long)nblk * pix != HW) return SKP_E_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(skp_gn_from_blocks_kernel, dim3(N * G), dim3(256), 0, st, a, bs, nblk, pix, mean, rstd);
+    rc = skp_launch_status();
+    if (rc) return rc;
+    long blocks = (a.L / 4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(skp_gn_apply_kernel, dim3((unsigned)blocks, N * G), dim3(256), 0, st, a, (const float*)nullptr, y, mean,
+                       rstd);
     return skp_launch_status();
 }
 

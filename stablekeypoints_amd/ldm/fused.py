@@ -23,15 +23,16 @@ def _resnet_forward(m: ResnetBlock2D):
     def forward(x, temb=None):
         if not ops.group_norm_supported(x, m.norm1.num_groups):
             return orig(x, temb)
-        h = ops.group_norm_silu(x, m.norm1)
-        h = ops.conv3x3_auto(h, m.conv1.weight)                          # bias folded into norm2's offset
+        h = ops.group_norm_silu(x, m.norm1)                              # (statistics from x's producer when it left them)
+        h = ops.conv3x3_auto(h, m.conv1.weight, want_stats=True)         # bias folded into norm2's offset
         off = m.conv1.bias[None, :].expand(x.shape[0], -1)
         if m.time_emb_proj is not None and temb is not None:
             off = off + m.time_emb_proj(F.silu(temb))
         h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
         if m.conv_shortcut is not None:
             x = m.conv_shortcut(x)
-        return ops.conv3x3_auto(h, m.conv2.weight, m.conv2.bias, residual=x)   # bias + shortcut in the conv epilogue
+        # bias + shortcut in the conv epilogue; its block sums serve the next block's first norm
+        return ops.conv3x3_auto(h, m.conv2.weight, m.conv2.bias, residual=x, want_stats=True)
     return forward
 
 
@@ -74,7 +75,7 @@ def _downsample_forward(m):
         needs_grad = torch.is_grad_enabled() and x.requires_grad
         if (not needs_grad and not m.conv.weight.requires_grad and m.conv.stride == (2, 2)
                 and ops.conv3x3_s2_supported(x, m.conv.weight)):
-            return ops.conv3x3_s2(x, m.conv.weight, m.conv.bias, pad=0 if m.padding == 0 else 1)
+            return ops.conv3x3_s2(x, m.conv.weight, m.conv.bias, pad=0 if m.padding == 0 else 1, want_stats=True)
         return orig(x)
     return forward
 

@@ -359,18 +359,26 @@ class GroupNormSiLUFn(torch.autograd.Function):
     """y = act(GroupNorm(x + off[:, :, None, None])) with act = SiLU or identity; gamma/beta/off frozen."""
 
     @staticmethod
-    def forward(ctx, x, off, gamma, beta, groups: int, eps: float, silu: bool):
+    def forward(ctx, x, off, gamma, beta, groups: int, eps: float, silu: bool, blocks=None):
         x = _dev(x, "x")
         Nn, C, Hh, Ww = x.shape
         off_c = _dev(off.reshape(Nn, C), "off") if off is not None else None
         y = torch.empty_like(x)
         mean = torch.empty(Nn, groups, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        ws = torch.empty(Nn * groups * 64 * 3, device=x.device, dtype=torch.float32)
-        N.check(N.lib().skp_group_norm_fwd_f32(x.data_ptr(), off_c.data_ptr() if off_c is not None else None,
-                                               gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                               rstd.data_ptr(), ws.data_ptr(), Nn, C, groups, Hh * Ww, float(eps),
-                                               int(silu), _stream()), "skp_group_norm_fwd_f32")
+        if blocks is not None:                       # statistics from the producing convolution's epilogue
+            bs, nblk, pix = blocks
+            N.check(N.lib().skp_group_norm_fwd_blocks_f32(x.data_ptr(), off_c.data_ptr() if off_c is not None else None,
+                                                          gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                          rstd.data_ptr(), bs.data_ptr(), int(nblk), int(pix), Nn, C, groups,
+                                                          Hh * Ww, float(eps), int(silu), _stream()),
+                    "skp_group_norm_fwd_blocks_f32")
+        else:
+            ws = torch.empty(Nn * groups * 64 * 3, device=x.device, dtype=torch.float32)
+            N.check(N.lib().skp_group_norm_fwd_f32(x.data_ptr(), off_c.data_ptr() if off_c is not None else None,
+                                                   gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), ws.data_ptr(), Nn, C, groups, Hh * Ww, float(eps),
+                                                   int(silu), _stream()), "skp_group_norm_fwd_f32")
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, off_c if off_c is not None else x.new_empty(0), gamma, beta, mean, rstd)
         ctx.meta = (groups, float(eps), bool(silu), off_c is not None)
@@ -388,11 +396,20 @@ class GroupNormSiLUFn(torch.autograd.Function):
                                                beta.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                dx.data_ptr(), ws.data_ptr(), Nn, C, groups, Hh * Ww, eps, int(silu),
                                                _stream()), "skp_group_norm_bwd_f32")
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
+
+
+GN_FUSED_STATS = os.environ.get("SKP_GN_FUSED_STATS", "1") != "0"
 
 
 def group_norm_silu(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
-    return GroupNormSiLUFn.apply(x, off, norm.weight, norm.bias, norm.num_groups, norm.eps, silu)
+    """GroupNorm(+offset)(+SiLU).  If `x` is the output of one of this library's convolutions that left block sums
+    behind (`x._skp_blocks`, set by conv3x3_auto / conv3x3_s2), the statistics pass over `x` is skipped."""
+    blocks = getattr(x, "_skp_blocks", None) if GN_FUSED_STATS else None
+    if blocks is not None and (blocks[0].shape[0] != x.shape[0] or blocks[0].shape[1] != x.shape[1]
+                               or blocks[1] * blocks[2] != x.shape[2] * x.shape[3]):
+        blocks = None
+    return GroupNormSiLUFn.apply(x, off, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, blocks)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -531,9 +548,14 @@ def _wino4_filters(weight, backward):
     return U
 
 
-def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None, out=None):
+def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None, out=None, stats=None):
     B, ci, H, W = x.shape
     y = out if out is not None else torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    if stats is not None:                            # unsplit launch that also leaves the output's block sums behind
+        N.check(N.lib().skp_conv3x3_f4_stats_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                                 stats.data_ptr(), B, ci, cout, H, W, _stream()), "skp_conv3x3_f4_stats_f32")
+        return y
     nbytes = N.lib().skp_conv3x3_f4_workspace(B, ci, cout, H, W) if split else 0
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
     N.check(N.lib().skp_conv3x3_f4_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -563,7 +585,18 @@ def conv3x3_wanted(x_shape, w_shape):
     return conv3x3_f4_ok(x_shape, w_shape) or b * ((h + 1) // 2) * ((w + 1) // 2) >= 128
 
 
-def _conv3x3_run(x, weight, backward, bias, residual, cout):
+def conv3x3_stats_blocks(x_shape, w_shape) -> int:
+    """256-pixel blocks per image if the forward convolution of this shape can leave output statistics behind, else 0."""
+    if not (GN_FUSED_STATS and conv3x3_f4_ok(x_shape, w_shape)):
+        return 0
+    b, ci, h, w = (int(v) for v in x_shape)
+    co = int(w_shape[0])
+    if max(ci, co) * h * w * 4 * b >= 2 ** 31:           # chunked launches: keep the plain path
+        return 0
+    return int(N.lib().skp_conv3x3_f4_stats_blocks(b, ci, co, h, w))
+
+
+def _conv3x3_run(x, weight, backward, bias, residual, cout, stats=None):
     w_shape = (weight.shape[1], weight.shape[0], 3, 3) if backward else weight.shape
     f4 = conv3x3_f4_ok(x.shape, w_shape)
     U = _wino4_filters(weight, backward) if f4 else _wino_filters(weight, backward)
@@ -571,6 +604,8 @@ def _conv3x3_run(x, weight, backward, bias, residual, cout):
     B, ci, H, W = x.shape
     per_image = max(ci, cout) * H * W * 4
     chunk = max(1, (2 ** 31 - 1) // per_image)           # rows per launch under the kernels' 2 GiB addressing limit
+    if stats is not None:
+        return _conv3x3_f4_raw(x, U, bias, cout, residual=residual, stats=stats)
     if B <= chunk:
         return run(x, U, bias, cout, residual=residual)
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
@@ -585,12 +620,12 @@ class Conv3x3Fn(torch.autograd.Function):
     run with the rotated, transposed filter; the residual's gradient is dy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual=None):
+    def forward(ctx, x, weight, bias, residual=None, stats=None):
         x = _dev(x, "x")
         ctx.weight = weight
         if residual is not None:
             residual = _dev(residual, "residual")
-        return _conv3x3_run(x, weight, False, bias, residual, weight.shape[0])
+        return _conv3x3_run(x, weight, False, bias, residual, weight.shape[0], stats=stats)
 
     @staticmethod
     def backward(ctx, dy):
@@ -602,7 +637,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 dx = _conv3x3_run(_dev(dy, "dy"), w, True, None, None, ci)
             else:       # too few tiles for these kernels: library backward-data
                 dx = torch.nn.grad.conv2d_input((dy.shape[0], ci, dy.shape[2], dy.shape[3]), w, dy, padding=1)
-        return dx, None, None, (dy if ctx.needs_input_grad[3] else None)
+        return dx, None, None, (dy if ctx.needs_input_grad[3] else None), None
 
 
 def conv3x3(x, weight, bias=None, residual=None):
@@ -613,11 +648,17 @@ def conv3x3(x, weight, bias=None, residual=None):
     return Conv3x3Fn.apply(x, weight, bias, residual)
 
 
-def conv3x3_auto(x, weight, bias=None, residual=None):
+def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
     """The frozen blocks' 3x3 convolution (+ bias + residual): Winograd kernel where it is wanted, library
     convolution (and the fused bias+residual pass) otherwise."""
     frozen = not (weight.requires_grad or (bias is not None and bias.requires_grad))     # the kernels give no dW / db
     if frozen and x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
+        nblk = conv3x3_stats_blocks(x.shape, weight.shape) if want_stats else 0
+        if nblk:
+            stats = torch.empty(x.shape[0], weight.shape[0], nblk, 2, device=x.device, dtype=torch.float32)
+            y = Conv3x3Fn.apply(x, weight, bias, residual, stats)
+            y._skp_blocks = (stats, nblk, 256)           # consumed by group_norm_silu (same tensor object only)
+            return y
         return Conv3x3Fn.apply(x, weight, bias, residual)
     if residual is None:
         return torch.nn.functional.conv2d(x, weight, bias, padding=1)
@@ -639,7 +680,7 @@ def conv3x3_s2_supported(x, weight) -> bool:
             and w % 32 == 0 and max(b * ci * h * w, b * co * (h // 2) * (w // 2), 9 * ci * co) * 4 < 2 ** 31)
 
 
-def conv3x3_s2(x, weight, bias=None, pad: int = 0):
+def conv3x3_s2(x, weight, bias=None, pad: int = 0, want_stats: bool = False):
     """y = conv2d(zero-extended x, weight, bias, stride 2): pad = 0 is F.pad(x, (0,1,0,1)) + padding 0 (the VAE's
     Downsample2D), pad = 1 is padding 1.  No autograd: frozen weights and an input that needs no gradient."""
     x = _dev(x.detach(), "x")
@@ -659,6 +700,14 @@ def conv3x3_s2(x, weight, bias=None, pad: int = 0):
     B, ci, H, W = x.shape
     co = weight.shape[0]
     y = torch.empty(B, co, H // 2, W // 2, device=x.device, dtype=torch.float32)
+    if want_stats and GN_FUSED_STATS:
+        nblk = (H // 16) * (W // 32)
+        stats = torch.empty(B, co, nblk, 2, device=x.device, dtype=torch.float32)
+        N.check(N.lib().skp_conv3x3_s2_stats_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                 y.data_ptr(), stats.data_ptr(), B, ci, co, H, W, int(pad), _stream()),
+                "skp_conv3x3_s2_stats_f32")
+        y._skp_blocks = (stats, nblk, 128)
+        return y
     N.check(N.lib().skp_conv3x3_s2_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                        B, ci, co, H, W, int(pad), _stream()), "skp_conv3x3_s2_f32")
     return y

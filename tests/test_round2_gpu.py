@@ -464,3 +464,62 @@ def test_optimize_embedding_runs_on_sd2x_sdxl_trees(arch):
     assert (out.cpu() - ctx0).abs().max().item() > 1e-4
     out2 = optimize_embedding(ldm, args, controllers, n)            # default init follows the architecture's width
     assert out2.shape == (1, 24, width)
+
+
+def test_conv_epilogue_statistics_feed_group_norm(ops):
+    """GroupNorm statistics taken from the producing convolution's epilogue (block sums of the OUTPUT incl. bias / shortcut;
+    Winograd stride-1 forms and the stride-2 kernel) instead of a pass over the activation: block sums vs torch, and the
+    normalised result + input gradient vs the two-pass kernel and vs fp64."""
+    g = torch.Generator().manual_seed(41)
+    seen = 0
+    for (B, ci, co, H, W, with_res) in ((2, 32, 128, 32, 32, True), (2, 64, 64, 32, 64, False), (1, 128, 256, 64, 32, True),
+                                        (8, 32, 64, 128, 128, False), (4, 64, 128, 128, 64, True)):
+        x = torch.randn(B, ci, H, W, generator=g).cuda()
+        w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
+        b = torch.randn(co, generator=g).cuda()
+        res = torch.randn(B, co, H, W, generator=g).cuda() if with_res else None
+        y = ops.conv3x3_auto(x, w, b, residual=res, want_stats=True)
+        y_plain = ops.conv3x3_auto(x, w, b, residual=res)
+        assert torch.equal(y, y_plain) and not hasattr(y_plain, "_skp_blocks")
+        if ops.conv3x3_stats_blocks(x.shape, w.shape) == 0:        # split-K launch for this shape: no block sums, two-pass norm
+            assert not hasattr(y, "_skp_blocks")
+            continue
+        assert ops.conv3x3_stats_blocks(x.shape, w.shape) == H * W // 256
+        bs, nblk, pix = y._skp_blocks
+        seen += 1
+        # blocks are 16 consecutive 4x4 tiles in tile-raster order
+        t = y.reshape(B, co, H // 4, 4, W // 4, 4).permute(0, 1, 2, 4, 3, 5).reshape(B, co, nblk, 256).double()
+        torch.testing.assert_close(bs[..., 0].double(), t.sum(-1), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(bs[..., 1].double(), (t * t).sum(-1), rtol=1e-5, atol=1e-4)
+        norm = torch.nn.GroupNorm(32, co, eps=1e-6).cuda()
+        with torch.no_grad():
+            norm.weight.copy_(torch.randn(co, generator=g)); norm.bias.copy_(torch.randn(co, generator=g))
+        off = torch.randn(B, co, generator=g).cuda()
+        for o in (None, off):
+            yr = y.detach().clone().requires_grad_(True)                       # no block sums attached -> two-pass statistics
+            z_ref = ops.group_norm_silu(yr, norm, off=o)
+            yb = y.detach().clone().requires_grad_(True)
+            yb._skp_blocks = (bs, nblk, pix)
+            z = ops.group_norm_silu(yb, norm, off=o)
+            torch.testing.assert_close(z, z_ref, rtol=2e-5, atol=2e-5)
+            wgt = torch.randn_like(z)
+            (z * wgt).sum().backward(); (z_ref * wgt).sum().backward()
+            torch.testing.assert_close(yb.grad, yr.grad, rtol=1e-4, atol=2e-5 * yr.grad.abs().max().item())
+            yd = y.detach().cpu().double() + (0 if o is None else o.cpu().double()[:, :, None, None])
+            nd = torch.nn.GroupNorm(32, co, eps=1e-6).double()
+            nd.load_state_dict({k: v.cpu().double() for k, v in norm.state_dict().items()})
+            torch.testing.assert_close(z.detach().cpu().double(), torch.nn.functional.silu(nd(yd)), rtol=2e-5, atol=2e-5)
+    assert seen >= 3                                               # both workgroup forms (64- and 128-channel) were exercised
+    # stride-2 kernel: sums over 8x16-pixel output tiles
+    x = torch.randn(2, 32, 64, 64, generator=g).cuda(); w = (torch.randn(64, 32, 3, 3, generator=g) / 17).cuda(); b = torch.randn(64, generator=g).cuda()
+    with torch.no_grad():
+        y = ops.conv3x3_s2(x, w, b, pad=0, want_stats=True)
+        bs, nblk, pix = y._skp_blocks
+        assert (nblk, pix) == (4 * 2, 128)
+        t = y.reshape(2, 64, 4, 8, 2, 16).permute(0, 1, 2, 4, 3, 5).reshape(2, 64, nblk, 128).double()
+        torch.testing.assert_close(bs[..., 0].double(), t.sum(-1), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(bs[..., 1].double(), (t * t).sum(-1), rtol=1e-5, atol=1e-4)
+        norm = torch.nn.GroupNorm(32, 64, eps=1e-6).cuda()
+        z = ops.group_norm_silu(y, norm)
+        z_ref = ops.group_norm_silu(y.clone(), norm)
+        torch.testing.assert_close(z, z_ref, rtol=2e-5, atol=2e-5)
