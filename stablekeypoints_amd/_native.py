@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "skp_nchw_to_tokens_f32": [_vp, _vp, _i, _i, _i, _vp],
     "skp_tokens_to_nchw_f32": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "skp_flash_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_flash_attn_bwd_workspace": [_i, _i, _i, _i, _i, _i],
     "skp_flash_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "skp_self_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "skp_self_attn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

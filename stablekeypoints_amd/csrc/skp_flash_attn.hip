@@ -546,6 +546,211 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Fused backward (one pass over the (query tile, key block) pairs; S and dP are computed ONCE).
+//   Workgroup = 128 keys (wave w: keys 32 w .. 32 w + 31, K / V fragments in registers, lane = key), loop over 64-query tiles
+//   (Q, dO, lse2, D staged in LDS, next tile prefetched in registers):
+//     S = Q.K^T, dP = dO.V^T, P = exp2(S - lse2), dS = P (dP - D)                   (as in the dK/dV kernel)
+//     dV^T += dO^T.P, dK^T += Q^T.dS                                                (score registers are the B operand)
+//     dS is written to LDS as [query][key of the block] -- the transpose the dQ product needs --, then wave w computes
+//     dQ^T[c][n] = sum_{t < 128} K[t][c] dS[n][t] for ITS 16 queries over all 128 keys of the block (A = the block's K
+//     rows kept in LDS, B = one ds_read_b128 per 16 keys), complete for this key block, and stores it as a partial.
+//   dQ = scale * sum over key blocks of the partials: a second, memory-bound kernel adds them in fixed order (no atomics:
+//   bit-reproducible).  Issued MFMA tiles per 2048 (query, key) pairs: 448 (two-kernel form: 608; useful: 400).
+//   LDS: Q | dO tile 22.5 KB, K block 22.5 KB, dS exchange 33.8 KB, statistics 0.5 KB = 79.3 KB -> two workgroups per CU (d = 40).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+struct FA2F {
+    using F = FA2<D>;
+    static constexpr int KB = 128, QT = 64, LDX = KB + 4;
+    static constexpr int OFF_Q = 0, OFF_DO = F::TILE, OFF_K = 2 * F::TILE, OFF_X = OFF_K + KB * F::LDK, OFF_S = OFF_X + QT * LDX;
+    static constexpr int LDS_FLOATS = OFF_S + 128;
+};
+
+// D[b,h,n] = sum_c dO[b,n,h,c] * O[b,n,h,c]   (one wave per 64 rows of a head would waste lanes: one thread per (row, head))
+__global__ __launch_bounds__(256) void skp_fa2_rowdot_kernel(const float* __restrict__ o, const float* __restrict__ dout,
+                                                            float* __restrict__ Dbuf, int H, int N, int D, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;             // i = (b*H + h)*N + n
+    if (i >= total) return;
+    const long n = i % N, bh = i / N;
+    const int h = (int)(bh % H);
+    const long b = bh / H;
+    const size_t ro = ((size_t)b * N + n) * (size_t)(H * D) + (size_t)h * D;
+    float acc = 0.f;
+    for (int c = 0; c < D; c += 4) {
+        const f32x4 a = *(const f32x4*)(o + ro + c), d4 = *(const f32x4*)(dout + ro + c);
+        acc += (a[0] * d4[0] + a[1] * d4[1]) + (a[2] * d4[2] + a[3] * d4[3]);
+    }
+    Dbuf[i] = acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ Dbuf,
+                                                                   float* __restrict__ dqp, float* __restrict__ dk,
+                                                                   float* __restrict__ dv, int H, int N, int Nk, float scale) {
+    using F = FA2<D>;
+    using X = FA2F<D>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem + X::OFF_Q;
+    float* dOs = smem + X::OFF_DO;
+    float* Ks = smem + X::OFF_K;
+    float* Xs = smem + X::OFF_X;
+    float* Ls = smem + X::OFF_S;                              // lse2[64] | D[64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.x, b = blockIdx.z, h = blockIdx.y, C = H * D;
+    const int t0 = kb * X::KB;
+    const size_t hoff = (size_t)b * N * C + (size_t)h * D;     // self-attention: q, k, v, dout share [B, N, C]
+    const float* qg = q + hoff;
+    const float* dog = dout + hoff;
+    const size_t soff = ((size_t)b * H + h) * N;
+    const float sl2 = scale * SKP_LOG2E;
+
+    // the block's K rows into LDS (raw, for the dQ product); K / V fragments of this wave's 32 keys into registers
+    for (int idx = tid; idx < X::KB * F::Q4; idx += 256) {
+        const int t = idx / F::Q4, c4 = idx - t * F::Q4;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + t < Nk) val = *(const f32x4*)(k + ((size_t)b * Nk + t0 + t) * C + h * D + c4 * 4);
+        *(f32x4*)(Ks + t * F::LDK + c4 * 4) = val;
+    }
+    f32x2 kf[2][F::D8], vf[2][F::D8];
+    int trow[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = t0 + 32 * wave + 16 * tt + i16;
+        trow[tt] = t;
+        const size_t ro = ((size_t)b * Nk + (t < Nk ? t : Nk - 1)) * C + h * D + 2 * g;
+#pragma unroll
+        for (int jj = 0; jj < F::D8; ++jj) {
+            kf[tt][jj] = *(const f32x2*)(k + ro + 8 * jj) * sl2;
+            vf[tt][jj] = *(const f32x2*)(v + ro + 8 * jj);
+        }
+    }
+    f32x4 dka[F::CT][2], dva[F::CT][2];
+#pragma unroll
+    for (int ct = 0; ct < F::CT; ++ct)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) { dka[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto fetch_stats = [&](int q0) -> float {
+        const int i = tid & 63, n = q0 + i;
+        if (tid >= 128) return 0.f;
+        if (n >= N) return tid < 64 ? INFINITY : 0.f;           // missing rows: lse2 = +inf => P = 0
+        return tid < 64 ? lse[soff + n] * SKP_LOG2E : Dbuf[soff + n];
+    };
+    FA2Stage<D> stg;
+    stg.init(C, tid);
+    f32x4 qr[F::U], dr[F::U];
+    float st = fetch_stats(0);
+    fa2_fetch_tile<D>(qr, qg, C, 0, N, stg, tid);
+    fa2_fetch_tile<D>(dr, dog, C, 0, N, stg, tid);
+    fa2_put<D>(Qs, qr, stg);
+    fa2_put<D>(dOs, dr, stg);
+    if (tid < 128) Ls[tid] = st;
+    __syncthreads();
+
+    const size_t pstride = (size_t)gridDim.z * N * C;          // floats per key-block partial of dQ
+    float* dqb = dqp + (size_t)kb * pstride + hoff;
+    for (int q0 = 0; q0 < N; q0 += X::QT) {
+        const bool more = q0 + X::QT < N;
+        if (more) {                                             // next query tile: in flight under this tile's MFMAs
+            st = fetch_stats(q0 + X::QT);
+            fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, tid);
+            fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, tid);
+        }
+        f32x4 s[4][2], dp[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        fa2_rowdot<D, 4, 2>(Qs, kf, s, i16, g);                 // S[n][t]
+        fa2_rowdot<D, 4, 2>(dOs, vf, dp, i16, g);               // dP[n][t]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 l4 = *(const f32x4*)(Ls + 16 * nt + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(Ls + 64 + 16 * nt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const float pr = __builtin_amdgcn_exp2f(s[nt][tt][r] - l4[r]);
+                    s[nt][tt][r] = pr;                                   // P
+                    dp[nt][tt][r] = pr * (dp[nt][tt][r] - d4[r]);        // dS
+                }
+        }
+        fa2_colacc<D, 4, 2>(dOs, s, dva, i16, g);               // dV^T[c][t] += sum_n dO[n][c] P[n][t]
+        fa2_colacc<D, 4, 2>(Qs, dp, dka, i16, g);               // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
+        // dS -> LDS, [query n][key of the block]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    Xs[(16 * nt + 4 * g + r) * X::LDX + 32 * wave + 16 * tt + i16] = dp[nt][tt][r];
+        __syncthreads();                                       // dS complete; everyone is done with this tile's Q / dO
+        if (more) {
+            fa2_put<D>(Qs, qr, stg);
+            fa2_put<D>(dOs, dr, stg);
+            if (tid < 128) Ls[tid] = st;
+        }
+        // dQ^T[c][n] for queries 16 w .. 16 w + 15 over the block's 128 keys
+        f32x4 dqa[F::CT];
+#pragma unroll
+        for (int ct = 0; ct < F::CT; ++ct) dqa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* xrow = Xs + (16 * wave + i16) * X::LDX + 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < X::KB / 16; ++kt) {
+            const f32x4 bx = *(const f32x4*)(xrow + 16 * kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* krow = Ks + (16 * kt + 4 * g + r) * F::LDK + i16;
+#pragma unroll
+                for (int ct = 0; ct < F::CT; ++ct)
+                    dqa[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[16 * ct], bx[r], dqa[ct], 0, 0, 0);
+            }
+        }
+        {
+            const int n = q0 + 16 * wave + i16;
+            if (n < N) {
+                float* drow = dqb + (size_t)n * C;
+#pragma unroll
+                for (int ct = 0; ct < F::CT; ++ct) {
+                    const int c0 = 16 * ct + 4 * g;
+                    if (c0 < D) *(f32x4*)(drow + c0) = dqa[ct];
+                }
+            }
+        }
+        __syncthreads();                                       // next tile staged; the exchange buffer is free again
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = trow[tt];
+        if (t < Nk) {
+            const size_t ro = ((size_t)b * Nk + t) * C + h * D;
+#pragma unroll
+            for (int ct = 0; ct < F::CT; ++ct) {
+                const int c0 = 16 * ct + 4 * g;
+                if (c0 < D) {
+                    *(f32x4*)(dk + ro + c0) = dka[ct][tt] * scale;
+                    *(f32x4*)(dv + ro + c0) = dva[ct][tt];
+                }
+            }
+        }
+    }
+}
+
+// dq = scale * sum_kb part[kb]   (fixed order)
+__global__ __launch_bounds__(256) void skp_fa2_dq_reduce_kernel(const float* __restrict__ part, float* __restrict__ dq, long n4,
+                                                               long stride, int nkb, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = ((const f32x4*)part)[i];
+    for (int z = 1; z < nkb; ++z) acc += ((const f32x4*)(part + (size_t)z * stride))[i];
+    ((f32x4*)dq)[i] = acc * scale;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 template <int D, int NQT, int MINW, int OPT>
@@ -619,14 +824,57 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
     return skp_launch_status();
 }
 
-// workspace: B*H*N floats (D = rowsum(dO * O)); -100 when the head size is not built here
+static bool fa2_fused_ok(int Bk, int B, int N, int Nk, int d) {
+    const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
+    if (e && e[0] == '0') return false;
+    return d == 40 && Bk == B && N == Nk && N >= 1024;           // the big self-attention layers
+}
+
+// bytes of scratch the backward needs: D = rowsum(dO * O) [B,H,N], plus the per-key-block dQ partials of the fused form
+int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
+    int64_t fl = (int64_t)B * H * N;
+    if (fa2_fused_ok(Bk, B, N, Nk, d)) fl += (int64_t)((Nk + 127) / 128) * B * N * H * d;
+    return fl * (int64_t)sizeof(float);
+}
+
+template <int D>
+static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk,
+                                float scale, hipStream_t st) {
+    using X = FA2F<D>;
+    const size_t lds = (size_t)X::LDS_FLOATS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    float* Dbuf = ws;
+    float* part = ws + (size_t)B * H * N;
+    const long rows = (long)B * H * N;
+    hipLaunchKernelGGL(skp_fa2_rowdot_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, out, dout, Dbuf, H, N, D, rows);
+    int rc = skp_launch_status();
+    if (rc) return rc;
+    const int nkb = (Nk + X::KB - 1) / X::KB;
+    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
+                       N, Nk, scale);
+    rc = skp_launch_status();
+    if (rc) return rc;
+    const long n4 = (long)B * N * H * D / 4;
+    hipLaunchKernelGGL(skp_fa2_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, dq, n4,
+                       (long)B * N * H * D, nkb, scale);
+    return skp_launch_status();
+}
+
+// workspace: skp_fa2_bwd_workspace() bytes; -100 when the head size is not built here
 int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
                 float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d, float scale,
-                void* stream) {
+                int allow_fused, void* stream) {
     const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
+    if (allow_fused && fa2_fused_ok(Bk, B, N, Nk, d)) return fa2_launch_bwd_fused<40>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
     return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
     switch (d) {

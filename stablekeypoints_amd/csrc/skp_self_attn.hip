@@ -251,7 +251,9 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
                 int Nk, int d, float scale, void* stream);
 int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
                 float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
-                float scale, void* stream);
+                float scale, int allow_fused, void* stream);
+
+int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d);
 
 static bool sa_gen1() {                                         // SKP_FLASH_GEN=1 forces the first-generation kernels (A/B runs)
     const char* e = getenv("SKP_FLASH_GEN");
@@ -282,16 +284,32 @@ extern "C" int skp_flash_attn_fwd_f32(const float* q, const float* k, const floa
     return skp_launch_status();
 }
 
-/* workspace: B*H*N floats (D = rowsum(dO*O)) */
+extern "C" int64_t skp_flash_attn_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
+    if (B <= 0 || H <= 0 || N <= 0 || Nk <= 0 || d <= 0 || (Bk != 1 && Bk != B)) return SKP_E_BADARG;
+    if (sa_gen1()) return (int64_t)B * H * N * (int64_t)sizeof(float);
+    return skp_fa2_bwd_workspace(B, Bk, H, N, Nk, d);
+}
+
+static int flash_bwd_impl(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
+                          float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
+                          float scale, int allow_fused, void* stream);
+
+/* workspace: skp_flash_attn_bwd_workspace() bytes */
 extern "C" int skp_flash_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
                                       const float* dout, const float* lse, float* dq, float* dk, float* dv,
                                       float* workspace, int B, int Bk, int H, int N, int Nk, int d, float scale,
                                       void* stream) {
+    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, 1, stream);
+}
+
+static int flash_bwd_impl(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
+                          float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
+                          float scale, int allow_fused, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return SKP_E_BADARG;
     int rc = sa_check(B, Bk, H, N, Nk, d);
     if (rc) return rc;
     if (!sa_gen1()) {
-        rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, stream);
+        rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, allow_fused, stream);
         if (rc != -100) return rc;
     }
     const int kvb = Bk == 1 ? 0 : 1;
@@ -331,5 +349,6 @@ extern "C" int skp_self_attn_fwd_f32(const float* q, const float* k, const float
 extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
                                      const float* dout, const float* lse, float* dq, float* dk, float* dv,
                                      float* workspace, int B, int H, int N, int d, float scale, void* stream) {
-    return skp_flash_attn_bwd_f32(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, B, H, N, N, d, scale, stream);
+    // B*H*N-float workspace contract of this entry point: the two-kernel form only
+    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, B, H, N, N, d, scale, 0, stream);
 }

@@ -447,7 +447,10 @@ class FlashAttnFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dk = torch.empty(B, Nk, C, device=q.device, dtype=torch.float32)
         dv = torch.empty_like(dk)
-        ws = torch.empty(B * heads * Nq, device=q.device, dtype=torch.float32)
+        nbytes = N.lib().skp_flash_attn_bwd_workspace(B, Bk, heads, Nq, Nk, C // heads)
+        if nbytes < 0:
+            N.check(int(nbytes), "skp_flash_attn_bwd_workspace")
+        ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
         N.check(N.lib().skp_flash_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                                lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(),
                                                B, Bk, heads, Nq, Nk, C // heads, scale, _stream()), "skp_flash_attn_bwd_f32")

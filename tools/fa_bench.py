@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """A/B timing + cross-check of the flash-attention kernel generations / tile variants at the step's launch shapes.
     python tools/fa_bench.py [--rows 8] [--iters 10] [--bwd]
-Environment switches read by the library per launch: SKP_FLASH_GEN=1 (first generation), SKP_FA2_VARIANT=n."""
+Environment switches read by the library per launch: SKP_FLASH_GEN=1 (first generation), SKP_FA2_VARIANT=n,
+SKP_FA2_FUSED=0 (two-kernel backward; a variant written "n+2k" sets it)."""
 import argparse
 import os
 import sys
@@ -41,13 +42,14 @@ def main():
         q, k, v, w = (torch.randn(B, N, H * d, generator=g).to(dev) for _ in range(4))
         q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
         flops = 4.0 * N * N * d * B * H
-        ref = None
+        ref = gref = None
         for var in a.variants.split(","):
             if var == "gen1":
                 os.environ["SKP_FLASH_GEN"] = "1"
             else:
                 os.environ["SKP_FLASH_GEN"] = "0"
-                os.environ["SKP_FA2_VARIANT"] = var
+                os.environ["SKP_FA2_VARIANT"] = var.split("+")[0]
+            os.environ["SKP_FA2_FUSED"] = "0" if var.endswith("+2k") else "1"
             try:
                 out = ops.self_attention(q, k, v, H, d ** -0.5)
                 torch.cuda.synchronize()
@@ -55,7 +57,7 @@ def main():
                 print(f"N={N} H={H} d={d} variant {var}: {e}")
                 continue
             t = timed(lambda: ops.self_attention(q, k, v, H, d ** -0.5), a.iters)
-            line = f"N={N} H={H} d={d} B={B} variant {var:>4}: fwd {t * 1e3:8.3f} ms  {flops / t / 1e12:6.1f} TF/s ({flops / t / 1e12 / PEAK:.3f})"
+            line = f"N={N} H={H} d={d} B={B} variant {var:>5}: fwd {t * 1e3:8.3f} ms  {flops / t / 1e12:6.1f} TF/s ({flops / t / 1e12 / PEAK:.3f})"
             if ref is None:
                 ref = out.detach().clone()
             else:
@@ -64,6 +66,11 @@ def main():
                 o = ops.self_attention(q, k, v, H, d ** -0.5)
                 tb = timed(lambda: torch.autograd.grad(o, (q, k, v), w, retain_graph=True), max(3, a.iters // 2))
                 line += f" | bwd {tb * 1e3:8.3f} ms {2.5 * flops / tb / 1e12:6.1f} TF/s ({2.5 * flops / tb / 1e12 / PEAK:.3f})"
+                gr = [x.clone() for x in torch.autograd.grad(o, (q, k, v), w, retain_graph=True)]
+                if gref is None:
+                    gref = gr
+                else:
+                    line += "  grad diff " + "/".join(f"{float((x - y).abs().max()):.1e}" for x, y in zip(gr, gref))
             print(line, flush=True)
 
 
