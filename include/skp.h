@@ -17,7 +17,7 @@
  *   skp_cross_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (ordinary softmax(QK^T)V, cross layers)
  *   skp_self_attn_fwd_f32 / _bwd_f32        ptp_utils.py:493-506,540 (self-attention layers, flash-style)
  *   skp_flash_attn_fwd_f32 / _bwd_f32       ptp_utils.py:493-506,540 (any key count: cross layers with T > 128 tokens)
- *   skp_conv3x3[_f4]_f32 / skp_conv3x3_s2_f32  3x3 convolutions of the frozen UNet / VAE blocks (ptp_utils.py:227-229, 289-304)
+ *   skp_conv3x3[_f4]_f32 / skp_conv3x3_s2_f32 / skp_conv3x3_small_f32  3x3 convolutions of the frozen UNet / VAE blocks (ptp_utils.py:227-229, 289-304)
  *   skp_group_norm_fwd_f32 / _bwd_f32       GroupNorm+SiLU of the hooked UNet / VAE forward (ptp_utils.py:227-229, 289-304)
  *   skp_token_stats_f32                     eval.py:39-111 + ptp_utils.py:95-108
  *   skp_select_tokens                       ptp_utils.py:110-112,115-159
@@ -127,7 +127,7 @@ int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /
  * q, out: [B,N,H*d]; k, v: [Bk,Nk,H*d] with Bk in {1,B} (Bk == 1: one k/v shared by all rows, ptp_utils.py:229);
  * lse: [B,H,N] natural-log sum-exp.  d in {8,16,32,40,64,80,160}.
  * _bwd: dq [B,N,H*d], dk, dv [B,Nk,H*d] WRITTEN per batch row (the caller sums dk/dv over b when Bk == 1);
- * workspace: skp_flash_attn_bwd_workspace() bytes (>= B*H*N floats; the fused single-pass backward of the big 40-wide
+ * workspace: skp_flash_attn_bwd_workspace() bytes (>= B*H*N floats; the fused single-pass backward of the big 40- / 80-wide
  * self-attention layers adds per-key-block dQ partials).  Deterministic (no atomics).  skp_self_attn_bwd_f32 keeps its
  * B*H*N-float workspace contract and therefore always runs the two-kernel form. */
 int64_t skp_flash_attn_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d);
@@ -221,6 +221,13 @@ int skp_group_norm_fwd_blocks_f32(const float* x, const float* off, const float*
 int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int Cin, void* stream);
 int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
                        int pad, void* stream);
+
+/* 3x3 / stride 1 / padding 1 convolution with AT MOST FOUR input channels (the `conv_in` layers: VAE encoder 3 -> 128 on the
+ * image, ptp_utils.py:289-304; UNet 4 -> 320 on the latents, ptp_utils.py:227), forward, NCHW, bias folded in (may be NULL).
+ * Output-bandwidth bound VALU kernel (two pixels per thread, wave-uniform weights).  w: the module's own [Cout,Cin,3,3].
+ * Limits: Cin <= 4, W even, B <= 65535, else SKP_E_RANGE. */
+int skp_conv3x3_small_f32(const void* x, const void* w, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
+                          void* stream);
 
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0

@@ -556,7 +556,8 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
 //     rows kept in LDS, B = one ds_read_b128 per 16 keys), complete for this key block, and stores it as a partial.
 //   dQ = scale * sum over key blocks of the partials: a second, memory-bound kernel adds them in fixed order (no atomics:
 //   bit-reproducible).  Issued MFMA tiles per 2048 (query, key) pairs: 448 (two-kernel form: 608; useful: 400).
-//   LDS: Q | dO tile 22.5 KB, K block 22.5 KB, dS exchange 33.8 KB, statistics 0.5 KB = 79.3 KB -> two workgroups per CU (d = 40).
+//   LDS: Q | dO tile 22.5 KB, K block 22.5 KB, dS exchange 33.8 KB, statistics 0.5 KB = 79.3 KB -> two workgroups per CU (d = 40);
+//   d = 80: 117 KB and 380 registers -> one workgroup per CU (MINB = 1).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int D>
 struct FA2F {
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(256) void skp_fa2_rowdot_kernel(const float* __rest
     Dbuf[i] = acc;
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
+template <int D, int MINB>
+__global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqp, float* __restrict__ dk,
@@ -827,7 +828,9 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
 static bool fa2_fused_ok(int Bk, int B, int N, int Nk, int d) {
     const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
     if (e && e[0] == '0') return false;
-    return d == 40 && Bk == B && N == Nk && N >= 1024;           // the big self-attention layers
+    // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 80-wide: one per CU (117 KB), still 0.42 -> 0.55 of
+    // peak at N = 1024.  64-wide heads at one workgroup per CU only tie the two-kernel form (0.58) and stay there.
+    return (d == 40 || d == 80) && Bk == B && N == Nk && N >= 1024;   // the big self-attention layers
 }
 
 // bytes of scratch the backward needs: D = rowsum(dO * O) [B,H,N], plus the per-key-block dQ partials of the fused form
@@ -837,7 +840,7 @@ int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     return fl * (int64_t)sizeof(float);
 }
 
-template <int D>
+template <int D, int MINB>
 static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                 const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk,
                                 float scale, hipStream_t st) {
@@ -845,7 +848,7 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     const size_t lds = (size_t)X::LDS_FLOATS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
@@ -856,7 +859,7 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     int rc = skp_launch_status();
     if (rc) return rc;
     const int nkb = (Nk + X::KB - 1) / X::KB;
-    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
+    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
                        N, Nk, scale);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -874,7 +877,10 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
     hipStream_t st = (hipStream_t)stream;
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
-    if (allow_fused && fa2_fused_ok(Bk, B, N, Nk, d)) return fa2_launch_bwd_fused<40>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+    if (allow_fused && fa2_fused_ok(Bk, B, N, Nk, d)) {
+        if (d == 40) return fa2_launch_bwd_fused<40, 2>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        return fa2_launch_bwd_fused<80, 1>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+    }
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
     return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
     switch (d) {

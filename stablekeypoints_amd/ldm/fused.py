@@ -29,11 +29,28 @@ def _resnet_forward(m: ResnetBlock2D):
         if m.time_emb_proj is not None and temb is not None:
             off = off + m.time_emb_proj(F.silu(temb))
         h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
+        bias = m.conv2.bias
         if m.conv_shortcut is not None:
-            x = m.conv_shortcut(x)
+            # 1x1 shortcut = one batched GEMM on the NCHW planes (no layout transposes); its bias joins conv2's
+            x, bias = ops.conv1x1_nobias(x, m.conv_shortcut.weight), _summed_bias(m)
         # bias + shortcut in the conv epilogue; its block sums serve the next block's first norm
-        return ops.conv3x3_auto(h, m.conv2.weight, m.conv2.bias, residual=x, want_stats=True)
+        return ops.conv3x3_auto(h, m.conv2.weight, bias, residual=x, want_stats=True)
     return forward
+
+
+def _summed_bias(m: ResnetBlock2D):
+    """conv2.bias + conv_shortcut.bias of a frozen block, cached against the parameters' versions."""
+    b2, bs = m.conv2.bias, m.conv_shortcut.bias
+    if bs is None:
+        return b2
+    if b2.requires_grad or bs.requires_grad:
+        return b2 + bs
+    tag = (b2._version, bs._version, b2.data_ptr(), bs.data_ptr())
+    hit = m.__dict__.get("_skp_bias_sum")
+    if hit is None or hit[0] != tag:
+        hit = (tag, (b2.detach() + bs.detach()))
+        m.__dict__["_skp_bias_sum"] = hit
+    return hit[1]
 
 
 def _transformer_forward(m: Transformer2DModel):

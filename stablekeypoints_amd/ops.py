@@ -663,12 +663,34 @@ def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
             y._skp_blocks = (stats, nblk, 256)           # consumed by group_norm_silu (same tensor object only)
             return y
         return Conv3x3Fn.apply(x, weight, bias, residual)
+    if (frozen and residual is None and x.is_cuda and x.dtype == torch.float32 and CONV3X3_MODE != "lib"
+            and weight.shape[1] <= 4 and x.shape[3] % 2 == 0 and not (torch.is_grad_enabled() and x.requires_grad)):
+        return conv3x3_small(x, weight, bias)                  # conv_in layers: output-bandwidth bound, own VALU kernel
     if residual is None:
         return torch.nn.functional.conv2d(x, weight, bias, padding=1)
     y = torch.nn.functional.conv2d(x, weight, None, padding=1)
     if bias is not None and y.is_cuda and y.dtype == torch.float32 and (y.shape[2] * y.shape[3]) % 4 == 0:
         return add_bias_residual(residual, y, bias)
     return (y + bias[None, :, None, None] if bias is not None else y) + residual
+
+
+def conv3x3_small(x, weight, bias=None):
+    """3x3 / stride 1 / padding 1 convolution with <= 4 input channels (the conv_in layers), forward only."""
+    x, w = _dev(x.detach(), "x"), _dev(weight.detach(), "weight")
+    B, ci, H, W = x.shape
+    y = torch.empty(B, w.shape[0], H, W, device=x.device, dtype=torch.float32)
+    bb = _dev(bias.detach(), "bias") if bias is not None else None
+    N.check(N.lib().skp_conv3x3_small_f32(x.data_ptr(), w.data_ptr(), bb.data_ptr() if bb is not None else None, y.data_ptr(),
+                                          B, ci, w.shape[0], H, W, _stream()), "skp_conv3x3_small_f32")
+    return y
+
+
+def conv1x1_nobias(x, weight):
+    """1x1 convolution without its bias as one batched GEMM over the NCHW planes: y[b] = W [Co,Ci] . x[b] [Ci, H*W]
+    (the library convolution wraps the same product in NCHW<->NHWC transposes).  Autograd: dx[b] = W^T . dy[b]."""
+    b, ci, h, w = x.shape
+    w2 = weight.reshape(weight.shape[0], ci)
+    return torch.matmul(w2, x.reshape(b, ci, h * w)).reshape(b, weight.shape[0], h, w)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -139,8 +139,9 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
     maps = collect_maps_batched(controller, layers=args.layers)  # [2n,T,R,R]
     tot_e = torch.zeros((), device=dev)
     tot_s = torch.zeros((), device=dev)
+    rows = maps.unbind(0)                                        # one backward node: the 2n map gradients are stacked once
     for i in range(n):
-        sharp, equiv, _ = image_losses(maps[i], maps[n + i], thetas[i].reshape(-1).tolist(), args)
+        sharp, equiv, _ = image_losses(rows[i], rows[n + i], thetas[i].reshape(-1).tolist(), args)
         tot_e = tot_e + equiv
         tot_s = tot_s + sharp
     loss = (tot_e * args.equivariance_attn_loss_weight + tot_s * args.sharpening_loss_weight) / denom

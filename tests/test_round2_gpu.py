@@ -526,18 +526,48 @@ def test_conv_epilogue_statistics_feed_group_norm(ops):
 
 
 def test_fused_attention_backward_matches_two_kernel_form_and_is_reproducible(ops, monkeypatch):
-    """The single-pass backward of the big 40-wide self-attention layers (dQ partials per key block, fixed-order
+    """The single-pass backward of the big 40- / 80-wide self-attention layers (dQ partials per key block, fixed-order
     reduction) against the two-kernel form on the same inputs, ragged query count included; run twice: same bits."""
     g = torch.Generator().manual_seed(21)
-    for B, N, H in ((2, 1024, 3), (1, 1190, 2)):
-        q, k, v, w = (torch.randn(B, N, H * 40, generator=g).cuda() for _ in range(4))
+    for B, N, H, d in ((2, 1024, 3, 40), (1, 1190, 2, 40), (2, 1024, 2, 80), (1, 1101, 3, 80)):
+        q, k, v, w = (torch.randn(B, N, H * d, generator=g).cuda() for _ in range(4))
         q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
         grads = {}
         for mode in ("1", "0", "1"):
             monkeypatch.setenv("SKP_FA2_FUSED", mode)
-            out = ops.self_attention(q, k, v, H, 40 ** -0.5)
+            out = ops.self_attention(q, k, v, H, d ** -0.5)
             grads.setdefault(mode, []).append([x.clone() for x in torch.autograd.grad(out, (q, k, v), w)])
         for a, b in zip(*grads["1"]):
             assert torch.equal(a, b)
         for a, b in zip(grads["1"][0], grads["0"][0]):
             torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-6 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,with_bias", [(2, 3, 128, 70, 96, True), (1, 4, 320, 64, 64, True), (3, 1, 5, 9, 2, False),
+                                                    (2, 2, 33, 31, 130, True)])
+def test_conv_in_small_channel_kernel_vs_library(ops, B, ci, co, H, W, with_bias):
+    """conv_in layers (<= 4 input channels, VAE 3 -> 128 / UNet 4 -> 320) on the VALU kernel vs the library convolution
+    evaluated in fp64."""
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, ci, H, W, generator=g).cuda()
+    w = torch.randn(co, ci, 3, 3, generator=g).cuda()
+    b = torch.randn(co, generator=g).cuda() if with_bias else None
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double() if with_bias else None, padding=1)
+    y = ops.conv3x3_small(x, w, b)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
+    with torch.no_grad():                                       # the dispatcher routes frozen no-grad conv_in calls here
+        y2 = ops.conv3x3_auto(x, w, b)
+    assert torch.equal(y, y2)
+
+
+def test_shortcut_as_batched_gemm_matches_conv1x1(ops):
+    g = torch.Generator().manual_seed(34)
+    x = torch.randn(2, 96, 12, 20, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(40, 96, 1, 1, generator=g).cuda()
+    dy = torch.randn(2, 40, 12, 20, generator=g).cuda()
+    y = ops.conv1x1_nobias(x, w)
+    ref = torch.nn.functional.conv2d(x.double(), w.double())
+    torch.testing.assert_close(y.double(), ref, rtol=1e-4, atol=1e-4)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    (gr,) = torch.autograd.grad(ref, x, dy.double())
+    torch.testing.assert_close(gx.double(), gr.double(), rtol=1e-4, atol=1e-4)
