@@ -369,6 +369,7 @@ def main():
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, min(image_size, 512), max(3, a.kernel_iters // 6), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
+        issue1, issue2 = ops.mfma_issue_rate(1, device=dev), ops.mfma_issue_rate(2, device=dev)
         conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}")
         map_traffic, map_src = measured_traffic("skp_attn_map_fwd_kernel")
         cfg_name = CONFIG_NAME.get(a.model, "reduced-width test model")
@@ -414,6 +415,12 @@ def main():
                                    "bwd_us": sa["bwd"] * 1e6, "bwd_achieved": sa_b / sa["bwd"] / 1e12,
                                    "bwd_frac": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF,
                                    "rows_per_launch": B, "dtype": "f32 MFMA"},
+            # what the matrix pipe sustains on THIS box for back-to-back independent fp32 MFMAs (no loads, no VALU work):
+            # the practical ceiling under the nominal peak the fractions above are quoted against
+            "mfma_issue_ceiling": {"unit": "TFLOP/s", "nominal_peak": F32_MATRIX_PEAK_TF,
+                                   "one_wave_per_simd": issue1, "two_waves_per_simd": issue2,
+                                   "note": "skp_probe_mfma_f32; the Winograd conv kernels hold one wave per SIMD "
+                                           "(288 accumulators), the attention kernels two"},
             "attention_roofline_frac": {"map_fwd_hbm": ach / HBM_PEAK_GBS, "map_bwd_hbm": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS,
                                         "self_attn_fwd_mfma": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
                                         "self_attn_bwd_mfma": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF},

@@ -229,6 +229,10 @@ int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, 
 int skp_conv3x3_small_f32(const void* x, const void* w, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
                           void* stream);
 
+/* Measurement aid (bench.py): sustained rate, in TFLOP/s, of back-to-back independent v_mfma_f32_16x16x4_f32 with
+ * `waves_per_simd` (1..4) resident waves on every SIMD.  Synchronises `stream`.  scratch: >= 256*4*256 floats. */
+int skp_probe_mfma_f32(int waves_per_simd, int iters, float* scratch, float* tflops, void* stream);
+
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0
  * _bwd writes dp [rows, 2*inner] = d loss / d p given dy [rows, inner]. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "skp_conv3x3_s2_filter_f32": [_vp, _vp, _i, _i, _vp],
     "skp_conv3x3_s2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_small_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "skp_probe_mfma_f32": [_i, _i, _vp, _vp, _vp],
     "skp_conv3x3_f4_stats_blocks": [_i, _i, _i, _i, _i],
     "skp_conv3x3_f4_stats_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_s2_stats_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

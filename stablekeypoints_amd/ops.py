@@ -685,6 +685,18 @@ def conv3x3_small(x, weight, bias=None):
     return y
 
 
+def mfma_issue_rate(waves_per_simd: int = 1, iters: int = 20000, device=None) -> float:
+    """Measurement aid: TFLOP/s of back-to-back independent fp32 MFMAs with `waves_per_simd` waves on every SIMD."""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    scratch = torch.empty(256 * 4 * 256, device=dev, dtype=torch.float32)
+    out = ctypes.c_float(0.0)
+    with torch.cuda.device(dev):
+        N.check(N.lib().skp_probe_mfma_f32(int(waves_per_simd), int(iters), scratch.data_ptr(), ctypes.addressof(out), _stream()),
+                "skp_probe_mfma_f32")
+    return float(out.value)
+
+
 def conv1x1_nobias(x, weight):
     """1x1 convolution without its bias as one batched GEMM over the NCHW planes: y[b] = W [Co,Ci] . x[b] [Ci, H*W]
     (the library convolution wraps the same product in NCHW<->NHWC transposes).  Autograd: dx[b] = W^T . dy[b]."""
