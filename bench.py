@@ -58,6 +58,9 @@ def parse():
                     help="full: SURVEY 8(d)'s complete protocol (C1 256^2 x 50 steps + 512^2 x 3 steps + thread sweep; minutes)")
     ap.add_argument("--cpu-image-size", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the best of a short sweep over {32,64,128}")
+    ap.add_argument("--emulated-f32", action="store_true",
+                    help="EXPERIMENT (separate line, never the bench of record): frozen nn.Linear GEMMs on the bf16 matrix "
+                         "cores with three-term operand splits (csrc/skp_gemm_x3.hip)")
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
@@ -279,6 +282,8 @@ def main():
     # host threads: N ranks share the box's cores (the Python driver is the only CPU work of a rank)
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(1, world))))
     from stablekeypoints_amd import ops, _native
+    if a.emulated_f32:
+        ops.EMULATED_F32 = True                                  # read by fuse_norms when the frozen blocks are patched
     from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
     from stablekeypoints_amd.optimize import SyntheticImages, default_args, group_step
     from stablekeypoints_amd.optimize_token import load_ldm
@@ -383,7 +388,9 @@ def main():
                                    "is images_per_rank x N" if a.scaling == "weak" else
                                    "strong: the global batch is fixed (global_batch images per optimizer step), each rank "
                                    "processes global_batch / N of them"),
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32-emulated (bf16x3 nn.Linear GEMMs, everything else f32)" if a.emulated_f32 else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{cfg_name}: {a.model} architecture UNet+VAE (seeded synthetic weights), "
                                    f"{image_size}x{image_size}, batch {per_rank} images/rank/step x 2 views, "
                                    f"T={a.tokens} tokens x {width}, R={a.res}, top_k={a.top_k} of {a.candidates}, fp32 end to end",

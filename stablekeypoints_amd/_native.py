@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -50,6 +50,8 @@ SIGNATURES = {
     "skp_conv3x3_s2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_small_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_probe_mfma_f32": [_i, _i, _vp, _vp, _vp],
+    "skp_gemm_x3_split_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "skp_gemm_x3_nt_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp],
     "skp_conv3x3_f4_stats_blocks": [_i, _i, _i, _i, _i],
     "skp_conv3x3_f4_stats_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_s2_stats_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -697,6 +697,86 @@ def mfma_issue_rate(waves_per_simd: int = 1, iters: int = 20000, device=None) ->
     return float(out.value)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# EXPERIMENT (SKP_EMULATED_F32=1, separate bench line): frozen nn.Linear layers on the bf16 matrix cores with three-term
+# operand splits and six fp32-accumulated products (csrc/skp_gemm_x3.hip).  Off by default: fp32 MFMA / library GEMMs.
+# ---------------------------------------------------------------------------------------------------------
+EMULATED_F32 = os.environ.get("SKP_EMULATED_F32", "0") == "1"
+
+
+_X3_CACHE = {}
+
+
+def _x3_planes(weight, transpose: bool):
+    """bf16 (h, m, l) planes of a frozen [N, K] weight ([3][N][K]) or of its transpose ([3][K][N]).  Cached per storage
+    address + shape (call sites pass fresh views such as `conv.weight.flatten(1)`), re-made when the version moves."""
+    key = (weight.data_ptr(), tuple(weight.shape), weight.device, bool(transpose))
+    hit = _X3_CACHE.get(key)
+    if hit is not None and hit[0] == weight._version:
+        return hit[1]
+    w = _dev(weight.detach(), "weight")
+    n, k = w.shape
+    rows, cols = (k, n) if transpose else (n, k)
+    planes = torch.empty(3 * rows * cols, device=w.device, dtype=torch.bfloat16)
+    N.check(N.lib().skp_gemm_x3_split_f32(w.data_ptr(), planes.data_ptr(), rows, cols, int(transpose), _stream()),
+            "skp_gemm_x3_split_f32")
+    _X3_CACHE[key] = (weight._version, planes)
+    return planes
+
+
+X3_MIN_WIDTH = 2048     # output width from which the split kernel beats the library GEMM (profiles/r02_gemm_x3.md)
+
+
+def linear_x3_supported(x, weight) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 2 and not weight.requires_grad
+            and weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0 and x.shape[-1] == weight.shape[1])
+
+
+def linear_x3_wanted(x, weight) -> bool:
+    """Measured: the 128 x 128-tile kernel wins (1.1-1.3x) where the output is wide (GEGLU projections) and many rows
+    amortise its operand traffic; narrow outputs and short row counts stay on the library."""
+    rows = x.numel() // x.shape[-1]
+    return linear_x3_supported(x, weight) and weight.shape[0] >= X3_MIN_WIDTH and rows >= 2048
+
+
+class LinearX3Fn(torch.autograd.Function):
+    """y = x . W^T + b with frozen W [N, K], b: both GEMMs (forward, dx = dy . W) on the split-bf16 kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        k = weight.shape[1]
+        x2 = _dev(x.reshape(-1, k), "x")
+        m, n = x2.shape[0], weight.shape[0]
+        y = torch.empty(m, n, device=x.device, dtype=torch.float32)
+        bb = _dev(bias.detach(), "bias") if bias is not None else None
+        N.check(N.lib().skp_gemm_x3_nt_f32(x2.data_ptr(), _x3_planes(weight, False).data_ptr(),
+                                           bb.data_ptr() if bb is not None else None, y.data_ptr(), m, n, k, k, n, _stream()),
+                "skp_gemm_x3_nt_f32")
+        ctx.weight = weight
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        w = ctx.weight
+        n, k = w.shape
+        if k < X3_MIN_WIDTH:                                     # narrow dx: the library GEMM is faster there
+            return torch.matmul(dy, w), None, None
+        d2 = _dev(dy.reshape(-1, n), "dy")
+        m = d2.shape[0]
+        dx = torch.empty(m, k, device=dy.device, dtype=torch.float32)
+        N.check(N.lib().skp_gemm_x3_nt_f32(d2.data_ptr(), _x3_planes(w, True).data_ptr(), None, dx.data_ptr(), m, k, n, n, k,
+                                           _stream()), "skp_gemm_x3_nt_f32")
+        return dx.reshape(ctx.xshape), None, None
+
+
+def linear_auto(x, weight, bias=None):
+    """nn.Linear of a frozen block: library GEMM (fp32), or the split-bf16 experiment when SKP_EMULATED_F32=1."""
+    if EMULATED_F32 and linear_x3_wanted(x, weight) and (bias is None or not bias.requires_grad):
+        return LinearX3Fn.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def conv1x1_nobias(x, weight):
     """1x1 convolution without its bias as one batched GEMM over the NCHW planes: y[b] = W [Co,Ci] . x[b] [Ci, H*W]
     (the library convolution wraps the same product in NCHW<->NHWC transposes).  Autograd: dx[b] = W^T . dy[b]."""
