@@ -26,6 +26,8 @@
 #include "skp_common.h"
 #include <stdlib.h>
 
+#define SKP_MAP_XCAP 64           // slots per column in the quad-layer index lists (a column is touched by <= 5k/4 + 4 slots, k = R/s <= 32)
+
 struct MapArgs {
     const float* S[SKP_MAX_LAYERS];
     float* dS[SKP_MAX_LAYERS];
@@ -41,7 +43,24 @@ struct MapArgs {
     int ldt;                       // row stride (floats) of S / dS rows (>= NT of this launch)
     long m_bstride;                // floats between batch rows of M / dM
     int mode;                      // 0 self-contained | 1 statistics only | 2 apply external statistics
+    int quad[SKP_MAX_LAYERS];      // 1: every aligned group of four pixels shares its four tap columns (R = k*s, k % 8 == 0,
+                                   //    full tiles): one LDS read per token quad, the other three taps arrive by DPP
 };
+
+// value of quad lane K for all four lanes of an aligned lane quad (the compiler folds it into v_mul_f32_dpp)
+template <int K>
+__device__ __forceinline__ float skp_quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+// acc += (src of quad lane K) * w as ONE instruction: the DPP combine does not reach v_fmac_f32 (it sees the VOP3 fma),
+// so the VOP2 DPP form is written out.  `src` must come from memory (LDS / VMEM return), not from a VALU instruction
+// right before (DPP read-after-VALU-write needs wait states the assembler does not insert for inline text).
+template <int K>
+__device__ __forceinline__ void skp_quad_fmac(float& acc, float src, float w) {
+    if (K == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(w));
+    if (K == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(w));
+    if (K == 3) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(w));
+}
 
 // lane -> pixel of the row-aligned tile
 struct Tile { int y0, seg, ry, x, th_eff; bool valid; };
@@ -112,9 +131,10 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
         int cx[4]; float wx[4];
         skp_cubic_taps(tl.x, ratio, s, cx, wx);
         int base[4];
-        f32x2 w2[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { base[i] = (tl.ry * s + cx[i]) * TS; w2[i] = f32x2{wx[i], wx[i]}; }
+        for (int i = 0; i < 4; ++i) base[i] = (tl.ry * s + cx[i]) * TS;
+        const bool quad = a.quad[l] != 0;
+        const int base_own = base[tid & 3];
         __syncthreads();                                       // previous layer done with the tables (and raw rows)
         if (tid < tl.th_eff) {
             int cy[4]; float wy[4];
@@ -135,14 +155,29 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
             // token quads: one ds_read_b128 per tap per 4 tokens (256 B/clk LDS form), packed fp32 math
 #pragma unroll
             for (int q = 0; q < NT / 4; ++q) {
-                const f32x4 t0 = *(const f32x4*)(Vt + base[0] + 4 * q);
-                const f32x4 t1 = *(const f32x4*)(Vt + base[1] + 4 * q);
-                const f32x4 t2 = *(const f32x4*)(Vt + base[2] + 4 * q);
-                const f32x4 t3 = *(const f32x4*)(Vt + base[3] + 4 * q);
-                f32x4 v = wx[0] * t0;
-                v = wx[1] * t1 + v;
-                v = wx[2] * t2 + v;
-                v = wx[3] * t3 + v;
+                f32x4 v;
+                if (quad) {
+                    // the four lanes of a quad need the same four columns: lane j fetches column cx[j], the taps are
+                    // quad broadcasts folded into the fmas (a quarter of the LDS reads, same VALU count)
+                    const f32x4 own = *(const f32x4*)(Vt + base_own + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float acc1 = skp_quad_bcast<0>(own[e]) * wx[0];
+                        skp_quad_fmac<1>(acc1, own[e], wx[1]);
+                        skp_quad_fmac<2>(acc1, own[e], wx[2]);
+                        skp_quad_fmac<3>(acc1, own[e], wx[3]);
+                        v[e] = acc1;
+                    }
+                } else {
+                    const f32x4 t0 = *(const f32x4*)(Vt + base[0] + 4 * q);
+                    const f32x4 t1 = *(const f32x4*)(Vt + base[1] + 4 * q);
+                    const f32x4 t2 = *(const f32x4*)(Vt + base[2] + 4 * q);
+                    const f32x4 t3 = *(const f32x4*)(Vt + base[3] + 4 * q);
+                    v = wx[0] * t0;
+                    v = wx[1] * t1 + v;
+                    v = wx[2] * t2 + v;
+                    v = wx[3] * t3 + v;
+                }
                 if (4 * q >= NT - 16) {                         // NT = 16*ceil(T/16): only the last 16 can be pads
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -483,7 +518,8 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, f
 }
 
 // Backward, kernel A.  LDS: Vt | dSx[256][TC+1] | Wt[smax][TW] | xlo[smax] xhi[smax] | row tables.
-template <int NT, int MODE>
+// QUAD selects the layer class a launch covers (a.quad[l]): the two H-phase / adjoint forms do not fit one register budget
+template <int NT, int MODE, bool QUAD>
 __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const float* __restrict__ dM,
                                                                const float* __restrict__ lse_in,
                                                                float* __restrict__ dV, float* __restrict__ dot_io) {
@@ -511,6 +547,7 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
 
     int lh = 0;
     for (int l = 0; l < a.L; ++l) {
+        if ((a.quad[l] != 0) != QUAD) { lh += H; continue; }   // the other launch's layers
         const int s = a.s[l];
         const float ratio = (float)s / (float)R;
         int cx[4]; float wx[4];
@@ -518,6 +555,8 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
         int base[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) base[i] = (tl.ry * s + cx[i]) * TS;
+        constexpr bool quad = QUAD;
+        const int base_own = base[tid & 3];
         __syncthreads();                                       // previous layer done with tables / Wt
         if (tid < tl.th_eff) {
             int cy[4]; float wy[4];
@@ -525,15 +564,39 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
 #pragma unroll
             for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
         }
-        for (int i = tid; i < s * a.TW; i += 256) Wt[i] = 0.f;
-        if (tid < s) { xlo[tid] = 0x7fffffff; xhi[tid] = -1; }
-        __syncthreads();
-        if (tl.valid && tl.ry == 0) {                          // transpose of the horizontal taps: Wt[c][x]
+        // quad layers: lane i of a pixel quad ends up holding the quad's weighted sum for ITS tap column (below), so the
+        // gather of column c is a plain sum over the (pixel) slots whose tap column is c: an index list per column,
+        // built in ascending pixel order by one thread per column (deterministic), in the space of the weight table
+        int* lst = (int*)Wt;                                   // [s][X_CAP] slots, xhi[c] = count
+        float wq[4] = {0.f, 0.f, 0.f, 0.f};                    // weight quad lane j gives to MY tap column
+        if (quad) {
+            if (tid < s) {
+                int n = 0;
+                for (int x2 = 0; x2 < a.TW; ++x2) {
+                    int c2[4]; float w2[4];
+                    skp_cubic_taps(tl.seg * 256 + x2, ratio, s, c2, w2);
+                    if (c2[x2 & 3] == tid && n < SKP_MAP_XCAP) lst[tid * SKP_MAP_XCAP + n++] = x2;
+                }
+                xhi[tid] = n;
+            }
+            const int me = tid & 3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                      // same-lane adds are program-ordered => deterministic
-                atomicAdd(&Wt[cx[i] * a.TW + xl], wx[i]);
-                atomicMin(&xlo[cx[i]], xl);
-                atomicMax(&xhi[cx[i]], xl);
+            for (int k = 0; k < 4; ++k) {
+                const float c0 = skp_quad_bcast<0>(wx[k]), c1 = skp_quad_bcast<1>(wx[k]);
+                const float c2 = skp_quad_bcast<2>(wx[k]), c3 = skp_quad_bcast<3>(wx[k]);
+                if (me == k) { wq[0] = c0; wq[1] = c1; wq[2] = c2; wq[3] = c3; }
+            }
+        } else {
+            for (int i = tid; i < s * a.TW; i += 256) Wt[i] = 0.f;
+            if (tid < s) { xlo[tid] = 0x7fffffff; xhi[tid] = -1; }
+            __syncthreads();
+            if (tl.valid && tl.ry == 0) {                      // transpose of the horizontal taps: Wt[c][x]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {                  // same-lane adds are program-ordered => deterministic
+                    atomicAdd(&Wt[cx[i] * a.TW + xl], wx[i]);
+                    atomicMin(&xlo[cx[i]], xl);
+                    atomicMax(&xhi[cx[i]], xl);
+                }
             }
         }
         const int rc = tl.th_eff * s;
@@ -549,14 +612,27 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
             f32x4 dot4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < NT / 4; ++q) {                  // token quads: ds_read_b128 per tap, packed fp32 math
-                const f32x4 t0 = *(const f32x4*)(Vt + base[0] + 4 * q);
-                const f32x4 t1 = *(const f32x4*)(Vt + base[1] + 4 * q);
-                const f32x4 t2 = *(const f32x4*)(Vt + base[2] + 4 * q);
-                const f32x4 t3 = *(const f32x4*)(Vt + base[3] + 4 * q);
-                f32x4 v = wx[0] * t0;
-                v = wx[1] * t1 + v;
-                v = wx[2] * t2 + v;
-                v = wx[3] * t3 + v;
+                f32x4 v;
+                if (quad) {                                     // one read per quad lane, taps by DPP (see the forward kernel)
+                    const f32x4 own = *(const f32x4*)(Vt + base_own + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float acc1 = skp_quad_bcast<0>(own[e]) * wx[0];
+                        skp_quad_fmac<1>(acc1, own[e], wx[1]);
+                        skp_quad_fmac<2>(acc1, own[e], wx[2]);
+                        skp_quad_fmac<3>(acc1, own[e], wx[3]);
+                        v[e] = acc1;
+                    }
+                } else {
+                    const f32x4 t0 = *(const f32x4*)(Vt + base[0] + 4 * q);
+                    const f32x4 t1 = *(const f32x4*)(Vt + base[1] + 4 * q);
+                    const f32x4 t2 = *(const f32x4*)(Vt + base[2] + 4 * q);
+                    const f32x4 t3 = *(const f32x4*)(Vt + base[3] + 4 * q);
+                    v = wx[0] * t0;
+                    v = wx[1] * t1 + v;
+                    v = wx[2] * t2 + v;
+                    v = wx[3] * t3 + v;
+                }
                 v = v - lse;
                 f32x4 pr = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1]), __builtin_amdgcn_exp2f(v[2]),
                             __builtin_amdgcn_exp2f(v[3])};
@@ -577,10 +653,24 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch) __syncthreads();                       // previous chunk's gather done
+                if (quad) {
+                    // lane i of each pixel quad: sum_j w_j[tap i] * dS_j  (four DPP fmas), stored in the lane's own slot
 #pragma unroll
-                for (int tt = 0; tt < TC; ++tt) {
-                    const int t = ch * TC + tt;
-                    dSx[tid * TSC + tt] = tl.valid ? sv[t] * (g[t] - dot) : 0.f;
+                    for (int tt = 0; tt < TC; ++tt) {
+                        const int t = ch * TC + tt;
+                        const float ds = sv[t] * (g[t] - dot);
+                        float pq = skp_quad_bcast<0>(ds) * wq[0];
+                        skp_quad_fmac<1>(pq, ds, wq[1]);
+                        skp_quad_fmac<2>(pq, ds, wq[2]);
+                        skp_quad_fmac<3>(pq, ds, wq[3]);
+                        dSx[tid * TSC + tt] = pq;
+                    }
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < TC; ++tt) {
+                        const int t = ch * TC + tt;
+                        dSx[tid * TSC + tt] = tl.valid ? sv[t] * (g[t] - dot) : 0.f;
+                    }
                 }
                 __syncthreads();
                 // gather: dV[row][c][t] = sum_x Wt[c][x] * dS[row][x][t]; each item = (row, c, 4 strided tokens)
@@ -589,15 +679,24 @@ __global__ __launch_bounds__(256) void skp_attn_map_bwd_kernel(MapArgs a, const 
                     const int r = it / TQ, tq = it - r * TQ;
                     const int row = (int)(((float)r + 0.5f) * inv_s);
                     const int c = r - row * s;
-                    const int lo = xlo[c], hi = xhi[c];
-                    const float* w = Wt + c * a.TW;
                     const float* d = dSx + (size_t)(row * a.TW) * TSC + tq;
                     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-                    for (int xx = lo; xx <= hi; ++xx) {
-                        const float ww = w[xx];
-                        const float* dd = d + xx * TSC;
-                        o0 = fmaf(ww, dd[0], o0); o1 = fmaf(ww, dd[TQ], o1);
-                        o2 = fmaf(ww, dd[2 * TQ], o2); o3 = fmaf(ww, dd[3 * TQ], o3);
+                    if (quad) {
+                        const int n = xhi[c];
+                        const int* li2 = lst + c * SKP_MAP_XCAP;
+                        for (int e = 0; e < n; ++e) {
+                            const float* dd = d + li2[e] * TSC;
+                            o0 += dd[0]; o1 += dd[TQ]; o2 += dd[2 * TQ]; o3 += dd[3 * TQ];
+                        }
+                    } else {
+                        const int lo = xlo[c], hi = xhi[c];
+                        const float* w = Wt + c * a.TW;
+                        for (int xx = lo; xx <= hi; ++xx) {
+                            const float ww = w[xx];
+                            const float* dd = d + xx * TSC;
+                            o0 = fmaf(ww, dd[0], o0); o1 = fmaf(ww, dd[TQ], o1);
+                            o2 = fmaf(ww, dd[2 * TQ], o2); o3 = fmaf(ww, dd[3 * TQ], o3);
+                        }
                     }
                     float* out = dVg + ((size_t)(row * a.segs + tl.seg) * s + c) * NT + ch * TC + tq;
                     out[0] = o0; out[TQ] = o1; out[2 * TQ] = o2; out[3 * TQ] = o3;
@@ -680,6 +779,10 @@ static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const 
         a.dS[l] = dS ? dS[l] : nullptr;
         if (dS && !dS[l]) return SKP_E_BADARG;
         a.s[l] = s[l];
+        a.quad[l] = 0;
+        if (R % s[l] == 0 && ((R / s[l]) % 8) == 0 && R / s[l] <= 32 && (R <= 256 ? 256 % R == 0 : R % 256 == 0) &&
+            (R <= 256 ? R : 256) >= SKP_MAP_XCAP)
+            a.quad[l] = 1;
         a.dv_off[l] = off;
         off += (long)H * R * a.segs * s[l] * nt;
         smax = s[l] > smax ? s[l] : smax;
@@ -692,6 +795,7 @@ static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const 
     else { a.TH2 = 1; a.TW2 = 128; a.segs2 = (R + 127) / 128; }
     a.vt2_floats = (a.TH2 * smax * (nt + 4) + 3) & ~3;
     a.inv_lh = 1.0f / (float)(L * H);
+    { const char* e = getenv("SKP_MAP_QUAD"); if (e && e[0] == '0') for (int l = 0; l < L; ++l) a.quad[l] = 0; }   // A/B switch
     return 0;
 }
 
@@ -791,20 +895,28 @@ extern "C" int skp_attn_map_bwd_ex_f32(const float* const* S, float* const* dS, 
     if (lds > 160 * 1024) return SKP_E_LDS;
     dim3 grid(B, n_tiles(a)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define SKP_BWD_M(NTV, MD)                                                                               \
+    bool any_quad = false, any_plain = false;                  // one launch per layer class (the map gradient is read by both)
+    for (int l = 0; l < L; ++l) { if (a.quad[l]) any_quad = true; else any_plain = true; }
+#define SKP_BWD_Q(NTV, MD, QD)                                                                           \
     {                                                                                                    \
         if (lds > 64 * 1024) {                                                                           \
-            hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_bwd_kernel<NTV, MD>,            \
+            hipError_t e = hipFuncSetAttribute((const void*)skp_attn_map_bwd_kernel<NTV, MD, QD>,        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
             if (e != hipSuccess) return (int)e;                                                          \
         }                                                                                                \
-        hipLaunchKernelGGL((skp_attn_map_bwd_kernel<NTV, MD>), grid, block, lds, st, a, dM, lse, workspace, dot_io); \
+        hipLaunchKernelGGL((skp_attn_map_bwd_kernel<NTV, MD, QD>), grid, block, lds, st, a, dM, lse, workspace, dot_io); \
+    }
+#define SKP_BWD_M(NTV, MD)                                                                               \
+    {                                                                                                    \
+        if (any_plain) SKP_BWD_Q(NTV, MD, false)                                                         \
+        if (any_quad) SKP_BWD_Q(NTV, MD, true)                                                           \
     }
 #define SKP_BWD(NTV)                                                                                     \
     if (mode == 0) SKP_BWD_M(NTV, 0) else if (mode == 1) SKP_BWD_M(NTV, 1) else SKP_BWD_M(NTV, 2)
     SKP_NT_SWITCH(nt, SKP_BWD)
 #undef SKP_BWD
 #undef SKP_BWD_M
+#undef SKP_BWD_Q
     rc = skp_launch_status();
     if (rc || mode == 1) return rc;
     VAdjArgs v{};
