@@ -127,7 +127,7 @@ int skp_attn_map_bwd_ex_f32(const float* const* S /*[host]*/, float* const* dS /
  * q, out: [B,N,H*d]; k, v: [Bk,Nk,H*d] with Bk in {1,B} (Bk == 1: one k/v shared by all rows, ptp_utils.py:229);
  * lse: [B,H,N] natural-log sum-exp.  d in {8,16,32,40,64,80,160}.
  * _bwd: dq [B,N,H*d], dk, dv [B,Nk,H*d] WRITTEN per batch row (the caller sums dk/dv over b when Bk == 1);
- * workspace: skp_flash_attn_bwd_workspace() bytes (>= B*H*N floats; the fused single-pass backward of the big 40- / 80-wide
+ * workspace: skp_flash_attn_bwd_workspace() bytes (>= B*H*N floats; the fused single-pass backward of the big 40- / 64- / 80-wide
  * self-attention layers adds per-key-block dQ partials).  Deterministic (no atomics).  skp_self_attn_bwd_f32 keeps its
  * B*H*N-float workspace contract and therefore always runs the two-kernel form. */
 int64_t skp_flash_attn_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d);

@@ -141,6 +141,28 @@ __device__ __forceinline__ void fa2_rowdot(const float* __restrict__ X, const f3
     }
 }
 
+// the same with the Y fragments read from LDS rows (Y + (16 nt + i16) * LDK): saves the D8 * NQT register pairs
+template <int D, int NKT, int NQT>
+__device__ __forceinline__ void fa2_rowdot_lds(const float* __restrict__ X, const float* __restrict__ Y, f32x4 (&acc)[NKT][NQT],
+                                               int i16, int g) {
+    using F = FA2<D>;
+#pragma unroll
+    for (int jj = 0; jj < F::D8; ++jj) {
+        f32x2 y[NQT];
+#pragma unroll
+        for (int nt = 0; nt < NQT; ++nt) y[nt] = *(const f32x2*)(Y + (16 * nt + i16) * F::LDK + 2 * g + 8 * jj);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const f32x2 a = *(const f32x2*)(X + (16 * kt + i16) * F::LDK + 2 * g + 8 * jj);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NQT; ++nt)
+                    acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], y[nt][m], acc[kt][nt], 0, 0, 0);
+        }
+    }
+}
+
 // o[ct][nt] += sum over the tile's rows t of X[t][16 ct + i16] * p[kt][nt][r]   (t = 16 kt + 4 g + r)
 template <int D, int NKT, int NQT>
 __device__ __forceinline__ void fa2_colacc(const float* __restrict__ X, const f32x4 (&p)[NKT][NQT],
@@ -559,12 +581,16 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
 //   LDS: Q | dO tile 22.5 KB, K block 22.5 KB, dS exchange 33.8 KB, statistics 0.5 KB = 79.3 KB -> two workgroups per CU (d = 40);
 //   d = 80: 117 KB and 380 registers -> one workgroup per CU (MINB = 1).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool OVL = false>
 struct FA2F {
     using F = FA2<D>;
     static constexpr int KB = 128, QT = 64, LDX = KB + 4;
-    static constexpr int OFF_Q = 0, OFF_DO = F::TILE, OFF_K = 2 * F::TILE, OFF_X = OFF_K + KB * F::LDK, OFF_S = OFF_X + QT * LDX;
+    // OVL: the dS exchange buffer lies over the Q | dO tiles (two more barriers per tile, 34 KB less LDS: two workgroups per CU
+    // at D = 64)
+    static constexpr int OFF_Q = 0, OFF_DO = F::TILE, OFF_K = 2 * F::TILE, OFF_X = OVL ? 0 : OFF_K + KB * F::LDK;
+    static constexpr int OFF_S = OVL ? OFF_K + KB * F::LDK : OFF_X + QT * LDX;
     static constexpr int LDS_FLOATS = OFF_S + 128;
+    static_assert(!OVL || QT * LDX <= 2 * F::TILE, "the exchange buffer must fit the Q | dO tiles");
 };
 
 // D[b,h,n] = sum_c dO[b,n,h,c] * O[b,n,h,c]   (one wave per 64 rows of a head would waste lanes: one thread per (row, head))
@@ -584,14 +610,14 @@ __global__ __launch_bounds__(256) void skp_fa2_rowdot_kernel(const float* __rest
     Dbuf[i] = acc;
 }
 
-template <int D, int MINB>
+template <int D, int MINB, bool OVL>
 __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqp, float* __restrict__ dk,
                                                                    float* __restrict__ dv, int H, int N, int Nk, float scale) {
     using F = FA2<D>;
-    using X = FA2F<D>;
+    using X = FA2F<D, OVL>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem + X::OFF_Q;
     float* dOs = smem + X::OFF_DO;
@@ -614,7 +640,9 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         if (t0 + t < Nk) val = *(const f32x4*)(k + ((size_t)b * Nk + t0 + t) * C + h * D + c4 * 4);
         *(f32x4*)(Ks + t * F::LDK + c4 * 4) = val;
     }
-    f32x2 kf[2][F::D8], vf[2][F::D8];
+    // OVL (64-wide heads): the K fragments of the S product are read from the block's LDS copy (raw; the scale moves into
+    // the exp2 argument) instead of living in registers -- with them the kernel does not fit two waves per SIMD
+    f32x2 kf[OVL ? 1 : 2][OVL ? 1 : F::D8], vf[2][F::D8];
     int trow[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -623,7 +651,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         const size_t ro = ((size_t)b * Nk + (t < Nk ? t : Nk - 1)) * C + h * D + 2 * g;
 #pragma unroll
         for (int jj = 0; jj < F::D8; ++jj) {
-            kf[tt][jj] = *(const f32x2*)(k + ro + 8 * jj) * sl2;
+            if (!OVL) kf[OVL ? 0 : tt][OVL ? 0 : jj] = *(const f32x2*)(k + ro + 8 * jj) * sl2;
             vf[tt][jj] = *(const f32x2*)(v + ro + 8 * jj);
         }
     }
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
     float* dqb = dqp + (size_t)kb * pstride + hoff;
     for (int q0 = 0; q0 < N; q0 += X::QT) {
         const bool more = q0 + X::QT < N;
-        if (more) {                                             // next query tile: in flight under this tile's MFMAs
+        if (!OVL && more) {                                     // next query tile: in flight under this tile's MFMAs
             st = fetch_stats(q0 + X::QT);
             fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, tid);
             fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, tid);
@@ -664,7 +692,8 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        fa2_rowdot<D, 4, 2>(Qs, kf, s, i16, g);                 // S[n][t]
+        if (OVL) fa2_rowdot_lds<D, 4, 2>(Qs, Ks + 32 * wave * F::LDK, s, i16, g);   // raw S[n][t]
+        else fa2_rowdot<D, 4, 2>(Qs, (const f32x2 (&)[2][F::D8])kf, s, i16, g);    // S[n][t] (scaled, log2 units)
         fa2_rowdot<D, 4, 2>(dOs, vf, dp, i16, g);               // dP[n][t]
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -674,7 +703,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    const float pr = __builtin_amdgcn_exp2f(s[nt][tt][r] - l4[r]);
+                    const float pr = __builtin_amdgcn_exp2f(OVL ? __builtin_fmaf(s[nt][tt][r], sl2, -l4[r]) : s[nt][tt][r] - l4[r]);
                     s[nt][tt][r] = pr;                                   // P
                     dp[nt][tt][r] = pr * (dp[nt][tt][r] - d4[r]);        // dS
                 }
@@ -682,6 +711,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         fa2_colacc<D, 4, 2>(dOs, s, dva, i16, g);               // dV^T[c][t] += sum_n dO[n][c] P[n][t]
         fa2_colacc<D, 4, 2>(Qs, dp, dka, i16, g);               // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
         // dS -> LDS, [query n][key of the block]
+        if (OVL) __syncthreads();                              // the exchange buffer lies over Q | dO: everyone is done reading them
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -689,8 +719,13 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
                     Xs[(16 * nt + 4 * g + r) * X::LDX + 32 * wave + 16 * tt + i16] = dp[nt][tt][r];
+        if (OVL && more) {                                     // the score registers are free now: fetch the next tile into them
+            st = fetch_stats(q0 + X::QT);
+            fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, tid);
+            fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, tid);
+        }
         __syncthreads();                                       // dS complete; everyone is done with this tile's Q / dO
-        if (more) {
+        if (!OVL && more) {
             fa2_put<D>(Qs, qr, stg);
             fa2_put<D>(dOs, dr, stg);
             if (tid < 128) Ls[tid] = st;
@@ -723,6 +758,14 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
             }
         }
         __syncthreads();                                       // next tile staged; the exchange buffer is free again
+        if (OVL) {
+            if (more) {
+                fa2_put<D>(Qs, qr, stg);
+                fa2_put<D>(dOs, dr, stg);
+                if (tid < 128) Ls[tid] = st;
+            }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -828,9 +871,10 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
 static bool fa2_fused_ok(int Bk, int B, int N, int Nk, int d) {
     const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
     if (e && e[0] == '0') return false;
-    // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 80-wide: one per CU (117 KB), still 0.42 -> 0.55 of
-    // peak at N = 1024.  64-wide heads at one workgroup per CU only tie the two-kernel form (0.58) and stay there.
-    return (d == 40 || d == 80) && Bk == B && N == Nk && N >= 1024;   // the big self-attention layers
+    // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 64-wide: two per CU with the dS exchange laid over the
+    // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: one per CU (117 KB),
+    // still 0.42 -> 0.55 at N = 1024.
+    return (d == 40 || d == 64 || d == 80) && Bk == B && N == Nk && N >= 1024;   // the big self-attention layers
 }
 
 // bytes of scratch the backward needs: D = rowsum(dO * O) [B,H,N], plus the per-key-block dQ partials of the fused form
@@ -840,15 +884,15 @@ int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     return fl * (int64_t)sizeof(float);
 }
 
-template <int D, int MINB>
+template <int D, int MINB, bool OVL>
 static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                 const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk,
                                 float scale, hipStream_t st) {
-    using X = FA2F<D>;
+    using X = FA2F<D, OVL>;
     const size_t lds = (size_t)X::LDS_FLOATS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB, OVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
@@ -859,7 +903,7 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     int rc = skp_launch_status();
     if (rc) return rc;
     const int nkb = (Nk + X::KB - 1) / X::KB;
-    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
+    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
                        N, Nk, scale);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -878,8 +922,9 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
     if (allow_fused && fa2_fused_ok(Bk, B, N, Nk, d)) {
-        if (d == 40) return fa2_launch_bwd_fused<40, 2>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
-        return fa2_launch_bwd_fused<80, 1>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        if (d == 40) return fa2_launch_bwd_fused<40, 2, false>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        if (d == 64) return fa2_launch_bwd_fused<64, 2, true>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        return fa2_launch_bwd_fused<80, 1, false>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
     }
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
     return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
