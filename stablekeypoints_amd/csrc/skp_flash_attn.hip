@@ -40,13 +40,13 @@ template <int D>
 struct FA2Stage {
     int goff[FA2<D>::U];      // element offset inside the global tile (row * C + 4 * c4), -1 = this thread has no slot u
     int loff[FA2<D>::U];      // float offset inside the LDS tile
-    __device__ __forceinline__ void init(int C, int tid) {
+    __device__ __forceinline__ void init(int C, int tid, int rows = FA2<D>::KT) {   // rows: tiles shorter than 64 rows
         using F = FA2<D>;
 #pragma unroll
         for (int u = 0; u < F::U; ++u) {
             const int idx = tid + 256 * u;
             const int t = idx / F::Q4, c4 = idx - t * F::Q4;
-            const bool ok = idx < F::KT * F::Q4;
+            const bool ok = idx < rows * F::Q4;
             goff[u] = t * C + c4 * 4;
             loff[u] = ok ? t * F::LDK + c4 * 4 : -1;
         }
@@ -581,16 +581,17 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
 //   LDS: Q | dO tile 22.5 KB, K block 22.5 KB, dS exchange 33.8 KB, statistics 0.5 KB = 79.3 KB -> two workgroups per CU (d = 40);
 //   d = 80: 117 KB and 380 registers -> one workgroup per CU (MINB = 1).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, bool OVL = false>
+template <int D, bool OVL = false, int NQ = 4>
 struct FA2F {
     using F = FA2<D>;
-    static constexpr int KB = 128, QT = 64, LDX = KB + 4;
+    static constexpr int KB = 128, QT = 16 * NQ, LDX = KB + 4;    // NQ = 3: 48-query tiles (80-wide heads: 75.8 KB with OVL)
     // OVL: the dS exchange buffer lies over the Q | dO tiles (two more barriers per tile, 34 KB less LDS: two workgroups per CU
     // at D = 64)
-    static constexpr int OFF_Q = 0, OFF_DO = F::TILE, OFF_K = 2 * F::TILE, OFF_X = OVL ? 0 : OFF_K + KB * F::LDK;
+    static constexpr int QTILE = QT * F::LDK;                   // floats per staged Q / dO tile
+    static constexpr int OFF_Q = 0, OFF_DO = QTILE, OFF_K = 2 * QTILE, OFF_X = OVL ? 0 : OFF_K + KB * F::LDK;
     static constexpr int OFF_S = OVL ? OFF_K + KB * F::LDK : OFF_X + QT * LDX;
     static constexpr int LDS_FLOATS = OFF_S + 128;
-    static_assert(!OVL || QT * LDX <= 2 * F::TILE, "the exchange buffer must fit the Q | dO tiles");
+    static_assert(!OVL || QT * LDX <= 2 * QTILE, "the exchange buffer must fit the Q | dO tiles");
 };
 
 // D[b,h,n] = sum_c dO[b,n,h,c] * O[b,n,h,c]   (one wave per 64 rows of a head would waste lanes: one thread per (row, head))
@@ -610,20 +611,20 @@ __global__ __launch_bounds__(256) void skp_fa2_rowdot_kernel(const float* __rest
     Dbuf[i] = acc;
 }
 
-template <int D, int MINB, bool OVL>
+template <int D, int MINB, bool OVL, int NQ>
 __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqp, float* __restrict__ dk,
                                                                    float* __restrict__ dv, int H, int N, int Nk, float scale) {
     using F = FA2<D>;
-    using X = FA2F<D, OVL>;
+    using X = FA2F<D, OVL, NQ>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem + X::OFF_Q;
     float* dOs = smem + X::OFF_DO;
     float* Ks = smem + X::OFF_K;
     float* Xs = smem + X::OFF_X;
-    float* Ls = smem + X::OFF_S;                              // lse2[64] | D[64]
+    float* Ls = smem + X::OFF_S;                              // lse2[QT] | D[QT] (at 0 and 64)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int kb = blockIdx.x, b = blockIdx.z, h = blockIdx.y, C = H * D;
     const int t0 = kb * X::KB;
@@ -664,11 +665,11 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
     auto fetch_stats = [&](int q0) -> float {
         const int i = tid & 63, n = q0 + i;
         if (tid >= 128) return 0.f;
-        if (n >= N) return tid < 64 ? INFINITY : 0.f;           // missing rows: lse2 = +inf => P = 0
+        if (n >= N || i >= X::QT) return tid < 64 ? INFINITY : 0.f;   // missing rows: lse2 = +inf => P = 0
         return tid < 64 ? lse[soff + n] * SKP_LOG2E : Dbuf[soff + n];
     };
     FA2Stage<D> stg;
-    stg.init(C, tid);
+    stg.init(C, tid, X::QT);
     f32x4 qr[F::U], dr[F::U];
     float st = fetch_stats(0);
     fa2_fetch_tile<D>(qr, qg, C, 0, N, stg, tid);
@@ -687,16 +688,16 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
             fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, tid);
             fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, tid);
         }
-        f32x4 s[4][2], dp[4][2];
+        f32x4 s[NQ][2], dp[NQ][2];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NQ; ++nt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if (OVL) fa2_rowdot_lds<D, 4, 2>(Qs, Ks + 32 * wave * F::LDK, s, i16, g);   // raw S[n][t]
-        else fa2_rowdot<D, 4, 2>(Qs, (const f32x2 (&)[2][F::D8])kf, s, i16, g);    // S[n][t] (scaled, log2 units)
-        fa2_rowdot<D, 4, 2>(dOs, vf, dp, i16, g);               // dP[n][t]
+        if (OVL) fa2_rowdot_lds<D, NQ, 2>(Qs, Ks + 32 * wave * F::LDK, s, i16, g);   // raw S[n][t]
+        else fa2_rowdot<D, NQ, 2>(Qs, (const f32x2 (&)[2][F::D8])kf, s, i16, g);    // S[n][t] (scaled, log2 units)
+        fa2_rowdot<D, NQ, 2>(dOs, vf, dp, i16, g);              // dP[n][t]
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NQ; ++nt) {
             const f32x4 l4 = *(const f32x4*)(Ls + 16 * nt + 4 * g);
             const f32x4 d4 = *(const f32x4*)(Ls + 64 + 16 * nt + 4 * g);
 #pragma unroll
@@ -708,12 +709,12 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
                     dp[nt][tt][r] = pr * (dp[nt][tt][r] - d4[r]);        // dS
                 }
         }
-        fa2_colacc<D, 4, 2>(dOs, s, dva, i16, g);               // dV^T[c][t] += sum_n dO[n][c] P[n][t]
-        fa2_colacc<D, 4, 2>(Qs, dp, dka, i16, g);               // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
+        fa2_colacc<D, NQ, 2>(dOs, s, dva, i16, g);               // dV^T[c][t] += sum_n dO[n][c] P[n][t]
+        fa2_colacc<D, NQ, 2>(Qs, dp, dka, i16, g);               // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
         // dS -> LDS, [query n][key of the block]
         if (OVL) __syncthreads();                              // the exchange buffer lies over Q | dO: everyone is done reading them
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NQ; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -730,23 +731,23 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
             fa2_put<D>(dOs, dr, stg);
             if (tid < 128) Ls[tid] = st;
         }
-        // dQ^T[c][n] for queries 16 w .. 16 w + 15 over the block's 128 keys
-        f32x4 dqa[F::CT];
+        // dQ^T[c][n] over the block's 128 keys
+        if (NQ == 4) {                                         // wave w: queries 16 w .. 16 w + 15, all channel tiles (one dS read per 16 keys)
+            f32x4 dqa[F::CT];
 #pragma unroll
-        for (int ct = 0; ct < F::CT; ++ct) dqa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* xrow = Xs + (16 * wave + i16) * X::LDX + 4 * g;
+            for (int ct = 0; ct < F::CT; ++ct) dqa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* xrow = Xs + (16 * wave + i16) * X::LDX + 4 * g;
 #pragma unroll
-        for (int kt = 0; kt < X::KB / 16; ++kt) {
-            const f32x4 bx = *(const f32x4*)(xrow + 16 * kt);
+            for (int kt = 0; kt < X::KB / 16; ++kt) {
+                const f32x4 bx = *(const f32x4*)(xrow + 16 * kt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* krow = Ks + (16 * kt + 4 * g + r) * F::LDK + i16;
+                for (int r = 0; r < 4; ++r) {
+                    const float* krow = Ks + (16 * kt + 4 * g + r) * F::LDK + i16;
 #pragma unroll
-                for (int ct = 0; ct < F::CT; ++ct)
-                    dqa[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[16 * ct], bx[r], dqa[ct], 0, 0, 0);
+                    for (int ct = 0; ct < F::CT; ++ct)
+                        dqa[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[16 * ct], bx[r], dqa[ct], 0, 0, 0);
+                }
             }
-        }
-        {
             const int n = q0 + 16 * wave + i16;
             if (n < N) {
                 float* drow = dqb + (size_t)n * C;
@@ -754,6 +755,27 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
                 for (int ct = 0; ct < F::CT; ++ct) {
                     const int c0 = 16 * ct + 4 * g;
                     if (c0 < D) *(f32x4*)(drow + c0) = dqa[ct];
+                }
+            }
+        } else {                                               // NQ query tiles x CT channel tiles dealt round-robin to the four waves
+            constexpr int NPAIR = NQ * F::CT;
+#pragma unroll
+            for (int j = 0; j < (NPAIR + 3) / 4; ++j) {
+                const int pair = wave + 4 * j;                  // wave-uniform
+                if (pair < NPAIR) {
+                    const int ct = pair / NQ, qt = pair - ct * NQ;
+                    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+                    const float* xrow = Xs + (16 * qt + i16) * X::LDX + 4 * g;
+                    const float* kcol = Ks + (4 * g) * F::LDK + 16 * ct + i16;
+#pragma unroll
+                    for (int kt = 0; kt < X::KB / 16; ++kt) {
+                        const f32x4 bx = *(const f32x4*)(xrow + 16 * kt);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kcol[(16 * kt + r) * F::LDK], bx[r], acc1, 0, 0, 0);
+                    }
+                    const int n = q0 + 16 * qt + i16, c0 = 16 * ct + 4 * g;
+                    if (n < N && c0 < D) *(f32x4*)(dqb + (size_t)n * C + c0) = acc1;
                 }
             }
         }
@@ -872,8 +894,9 @@ static bool fa2_fused_ok(int Bk, int B, int N, int Nk, int d) {
     const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
     if (e && e[0] == '0') return false;
     // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 64-wide: two per CU with the dS exchange laid over the
-    // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: one per CU (117 KB),
-    // still 0.42 -> 0.55 at N = 1024.
+    // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: the same with
+    // 48-query tiles (75.8 KB; 57 spilled registers): 0.42 -> 0.55 at N = 1024, 0.69 at N = 4096 (SKP_FA2_D80=1: the
+    // 64-query form at one workgroup per CU, 0.52 / 0.64).
     return (d == 40 || d == 64 || d == 80) && Bk == B && N == Nk && N >= 1024;   // the big self-attention layers
 }
 
@@ -884,15 +907,15 @@ int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     return fl * (int64_t)sizeof(float);
 }
 
-template <int D, int MINB, bool OVL>
+template <int D, int MINB, bool OVL, int NQ>
 static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                 const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk,
                                 float scale, hipStream_t st) {
-    using X = FA2F<D, OVL>;
+    using X = FA2F<D, OVL, NQ>;
     const size_t lds = (size_t)X::LDS_FLOATS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB, OVL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
@@ -903,7 +926,7 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     int rc = skp_launch_status();
     if (rc) return rc;
     const int nkb = (Nk + X::KB - 1) / X::KB;
-    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
+    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
                        N, Nk, scale);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -922,9 +945,10 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
     if (allow_fused && fa2_fused_ok(Bk, B, N, Nk, d)) {
-        if (d == 40) return fa2_launch_bwd_fused<40, 2, false>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
-        if (d == 64) return fa2_launch_bwd_fused<64, 2, true>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
-        return fa2_launch_bwd_fused<80, 1, false>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        if (d == 40) return fa2_launch_bwd_fused<40, 2, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        if (d == 64) return fa2_launch_bwd_fused<64, 2, true, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        { const char* e8 = getenv("SKP_FA2_D80"); if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st); }
+        return fa2_launch_bwd_fused<80, 2, true, 3>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
     }
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
     return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
