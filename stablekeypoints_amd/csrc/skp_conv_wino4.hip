@@ -20,6 +20,7 @@
 // them costs hundreds of spilled registers).  fp32 throughout; relative error ~1e-5 of the output maximum.
 #include <type_traits>
 #include "skp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -591,13 +592,21 @@ int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     const int wgs = ((tiles + 31) / 32) * ((Cout + 63) / 64);
     const int nsteps = Cin / 16;
     const double out_bytes = (double)B * Cout * H * W * 4;
+    if (const char* e = getenv("SKP_WINO_SPLIT")) {              // experiments: force the K split where it divides the stages
+        const int S = atoi(e);
+        if (S >= 1 && S <= 16 && nsteps % S == 0) return S;
+    }
     int best = 1;
     double best_cost = 1e30;
+    // measured stage times (us): the 128-channel form ~3.9, the 64-channel form ~5.6 (tools/conv_bench.py with SKP_WINO_SPLIT
+    // forced); the reduce pass streams (S + 1) x the output at ~8 TB/s (the partials are L2 / MALL resident)
+    const bool c128 = (Cout % 128 == 0) && tiles >= 256;
+    const double stage_us = c128 ? 3.9 : 5.6;
     for (int S = 1; S <= 16; ++S) {
         if (nsteps % S) continue;
         const int rounds = (wgs * S + 255) / 256;
-        double cost = rounds * (nsteps / S + 2.0) * 3.9;       // ~2 stages of prologue + epilogue per workgroup
-        if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 4.0e6;
+        double cost = rounds * (nsteps / S + 2.0) * stage_us;  // ~2 stages of prologue + epilogue per workgroup
+        if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
         if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
     }
     return best;

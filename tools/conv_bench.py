@@ -10,7 +10,7 @@ SHAPES = [  # name, B, Cin, Cout, H
     ("vae 512^2 128->128", 8, 128, 128, 512), ("vae 256^2 128->256", 8, 128, 256, 256),
     ("vae 256^2 256->256", 8, 256, 256, 256), ("vae 128^2 256->512", 8, 256, 512, 128),
     ("vae 128^2 512->512", 8, 512, 512, 128), ("vae 64^2 512->512", 8, 512, 512, 64),
-    ("unet 64^2 320->320", 8, 320, 320, 64), ("unet 32^2 320->640", 8, 320, 640, 32),
+    ("unet 64^2 320->320", 8, 320, 320, 64), ("unet 64^2 640->320", 8, 640, 320, 64), ("unet 64^2 960->320", 8, 960, 320, 64), ("unet 32^2 320->640", 8, 320, 640, 32),
     ("unet 32^2 640->640", 8, 640, 640, 32), ("unet 16^2 640->1280", 8, 640, 1280, 16),
     ("unet 16^2 1280->1280", 8, 1280, 1280, 16), ("unet 8^2 1280->1280", 8, 1280, 1280, 8),
     ("unet 16^2 2560->1280", 8, 2560, 1280, 16), ("unet 32^2 1920->640", 8, 1920, 640, 32),
