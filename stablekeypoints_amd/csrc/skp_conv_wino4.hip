@@ -585,11 +585,21 @@ __global__ void skp_wino4_reduce_kernel(const float* __restrict__ part, const fl
     ((f32x4*)y)[i] = acc;
 }
 
+// 128-channel workgroup form where there are enough tiles (measured: 12-16 % faster on the VAE / 32^2 UNet layers, slower at
+// 16^2 and below where the doubled filter traffic per tile dominates).  A ragged last channel group is fine (clamped filter
+// rows, guarded stores): the 320-channel UNet layers run 3 groups (17 % idle MFMA rows) and still gain from the form's
+// shorter stages (one patch per thread instead of two).
+static bool wino4_use_c128(int Cout, int tiles) {
+    if (const char* e = getenv("SKP_WINO_C128")) { if (e[0] == '0') return (Cout % 128 == 0) && tiles >= 256; }
+    return tiles >= 256 && (Cout % 128 == 0 || (Cout > 128 && Cout % 128 >= 64));
+}
+
 int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     if ((Cin % 16) || (Cout % 16) || (H % 4) || (W % 4)) return 0;
     const int tiles = B * (H / 4) * (W / 4);
-    const int wgs = ((tiles + 31) / 32) * ((Cout + 63) / 64);
+    const bool c128 = wino4_use_c128(Cout, tiles);
+    const int wgs = c128 ? ((tiles + 15) / 16) * ((Cout + 127) / 128) : ((tiles + 31) / 32) * ((Cout + 63) / 64);
     const int nsteps = Cin / 16;
     const double out_bytes = (double)B * Cout * H * W * 4;
     if (const char* e = getenv("SKP_WINO_SPLIT")) {              // experiments: force the K split where it divides the stages
@@ -600,7 +610,6 @@ int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     double best_cost = 1e30;
     // measured stage times (us): the 128-channel form ~3.9, the 64-channel form ~5.6 (tools/conv_bench.py with SKP_WINO_SPLIT
     // forced); the reduce pass streams (S + 1) x the output at ~8 TB/s (the partials are L2 / MALL resident)
-    const bool c128 = (Cout % 128 == 0) && tiles >= 256;
     const double stage_us = c128 ? 3.9 : 5.6;
     for (int S = 1; S <= 16; ++S) {
         if (nsteps % S) continue;
@@ -690,12 +699,10 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    // 128-channel form where there are enough tiles (measured: 12-16 % faster on the VAE / 32^2 UNet layers, slower at
-    // 16^2 and below where the doubled filter traffic per tile dominates)
-    const bool c128 = (Cout % 128 == 0) && a.nTiles >= 256;
+    const bool c128 = wino4_use_c128(Cout, a.nTiles);
     if (c128) {                                     // 128 channels x 16 tiles per workgroup
         a.ntb = (a.nTiles + 15) / 16;
-        a.ncg = Cout / 128;
+        a.ncg = (Cout + 127) / 128;
         a.tb_per_xcd = a.ntb >= 64 ? (a.ntb + 7) / 8 : 0;
         dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
         if (a.stats) hipLaunchKernelGGL(skp_wino4_conv_c128_kernel<true>, grid, dim3(256), lds_c, st, a);
