@@ -84,14 +84,13 @@ def _conv_forward(m: torch.nn.Conv2d):
 
 
 def _downsample_forward(m):
-    """Downsample2D: where no gradient is needed (the VAE encoder runs under no_grad) the stride-2 convolution, its zero
-    padding and its bias are one kernel (csrc/skp_conv_s2.hip); otherwise the module's own forward (library)."""
+    """Downsample2D: the stride-2 convolution, its zero padding and its bias are one kernel (csrc/skp_conv_s2.hip); where the
+    input needs a gradient (UNet) only the input gradient stays on the library.  Unsupported shapes: the module's own forward."""
     orig = m.forward
 
     def forward(x):
-        needs_grad = torch.is_grad_enabled() and x.requires_grad
-        if (not needs_grad and not m.conv.weight.requires_grad and m.conv.stride == (2, 2)
-                and ops.conv3x3_s2_supported(x, m.conv.weight)):
+        frozen = not (m.conv.weight.requires_grad or (m.conv.bias is not None and m.conv.bias.requires_grad))
+        if frozen and m.conv.stride == (2, 2) and ops.conv3x3_s2_supported(x, m.conv.weight):
             return ops.conv3x3_s2(x, m.conv.weight, m.conv.bias, pad=0 if m.padding == 0 else 1, want_stats=True)
         return orig(x)
     return forward

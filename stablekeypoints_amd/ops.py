@@ -797,12 +797,38 @@ def conv3x3_s2_supported(x, weight) -> bool:
             and w % 32 == 0 and max(b * ci * h * w, b * co * (h // 2) * (w // 2), 9 * ci * co) * 4 < 2 ** 31)
 
 
+class ConvS2Fn(torch.autograd.Function):
+    """Stride-2 3x3 convolution of a frozen UNet Downsample2D whose INPUT needs a gradient: forward on the direct MFMA
+    kernel, input gradient through the library's backward-data (a polyphase form of the kernel is not built)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad):
+        ctx.save_for_backward(weight)
+        ctx.xshape, ctx.pad = tuple(x.shape), int(pad)
+        return _conv3x3_s2_raw(x, weight, bias, pad, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        if ctx.pad == 1:
+            return torch.nn.grad.conv2d_input(ctx.xshape, w, dy.contiguous(), stride=2, padding=1), None, None, None
+        b, c, h, wd = ctx.xshape                                 # pad 0 = asymmetric (0,1,0,1) extension
+        dxp = torch.nn.grad.conv2d_input((b, c, h + 1, wd + 1), w, dy.contiguous(), stride=2, padding=0)
+        return dxp[:, :, :h, :wd], None, None, None
+
+
 def conv3x3_s2(x, weight, bias=None, pad: int = 0, want_stats: bool = False):
     """y = conv2d(zero-extended x, weight, bias, stride 2): pad = 0 is F.pad(x, (0,1,0,1)) + padding 0 (the VAE's
-    Downsample2D), pad = 1 is padding 1.  No autograd: frozen weights and an input that needs no gradient."""
+    Downsample2D), pad = 1 is padding 1.  Frozen weights; an input that needs a gradient goes through ConvS2Fn."""
+    if weight.requires_grad or (bias is not None and bias.requires_grad):
+        raise RuntimeError("conv3x3_s2: frozen weights only")
+    if torch.is_grad_enabled() and x.requires_grad:
+        return ConvS2Fn.apply(x, weight, bias, int(pad))
+    return _conv3x3_s2_raw(x, weight, bias, pad, want_stats)
+
+
+def _conv3x3_s2_raw(x, weight, bias, pad, want_stats):
     x = _dev(x.detach(), "x")
-    if weight.requires_grad or torch.is_grad_enabled() and x.requires_grad:
-        raise RuntimeError("conv3x3_s2 is forward-only")
     key = "_skp_s2"
     hit = getattr(weight, key, None)
     tag = (weight._version, weight.data_ptr())

@@ -617,3 +617,22 @@ def test_split_bf16_linear_autograd_and_dispatch(ops, monkeypatch):
     assert ops.linear_x3_wanted(x, w) and not ops.linear_x3_wanted(x, w[:320].contiguous()) and not ops.linear_x3_wanted(x[:, :100], w)
     monkeypatch.setattr(ops, "EMULATED_F32", False)
     assert torch.equal(ops.linear_auto(x, w, b), torch.nn.functional.linear(x, w, b))
+
+
+@pytest.mark.parametrize("pad", [1, 0])
+def test_stride2_conv_with_input_gradient(ops, pad):
+    """UNet Downsample2D: forward on the stride-2 kernel, input gradient through the library's backward-data; both against the
+    library convolution in fp64."""
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(2, 32, 32, 64, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(64, 32, 3, 3, generator=g) / 17.0).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    dy = torch.randn(2, 64, 16, 32, generator=g).cuda()
+    xd = x.detach().double().requires_grad_(True)
+    xin = torch.nn.functional.pad(xd, (0, 1, 0, 1)) if pad == 0 else xd
+    ref = torch.nn.functional.conv2d(xin, w.double(), b.double(), stride=2, padding=0 if pad == 0 else 1)
+    (gref,) = torch.autograd.grad(ref, xd, dy.double())
+    y = ops.conv3x3_s2(x, w, b, pad=pad)
+    (gx,) = torch.autograd.grad(y, x, dy)
+    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(gx.double(), gref, rtol=1e-4, atol=1e-4)
