@@ -777,6 +777,38 @@ def linear_auto(x, weight, bias=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class QKVProjFn(torch.autograd.Function):
+    """q, k, v = x.Wq^T, x.Wk^T, x.Wv^T of a frozen self-attention block (bias-free projections, ptp_utils.py:513-520).
+    The input gradient accumulates inside the GEMMs (dx = dq.Wq, then two beta = 1 GEMMs) instead of three GEMMs and two
+    add passes over [B, N, C]."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        ctx.save_for_backward(wq, wk, wv)
+        F = torch.nn.functional
+        return F.linear(x, wq), F.linear(x, wk), F.linear(x, wv)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        wq, wk, wv = ctx.saved_tensors
+        shp = dq.shape
+        dx = torch.mm(dq.reshape(-1, shp[-1]), wq)
+        dx.addmm_(dk.reshape(-1, shp[-1]), wk)
+        dx.addmm_(dv.reshape(-1, shp[-1]), wv)
+        return dx.reshape(*shp[:-1], wq.shape[1]), None, None, None
+
+
+QKV_ACCUM = os.environ.get("SKP_QKV_ACCUM", "1") != "0"       # A/B switch
+
+
+def qkv_proj(x, wq, wk, wv):
+    """Self-attention projections; frozen bias-free weights take the accumulate-in-GEMM backward."""
+    if QKV_ACCUM and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and not (wq.requires_grad or wk.requires_grad or wv.requires_grad):
+        return QKVProjFn.apply(x, wq, wk, wv)
+    F = torch.nn.functional
+    return F.linear(x, wq), F.linear(x, wk), F.linear(x, wv)
+
+
 def conv1x1_nobias(x, weight):
     """1x1 convolution without its bias as one batched GEMM over the NCHW planes: y[b] = W [Co,Ci] . x[b] [Ci, H*W]
     (the library convolution wraps the same product in NCHW<->NHWC transposes).  Autograd: dx[b] = W^T . dy[b]."""

@@ -115,10 +115,14 @@ def register_attention_control(model, controller, feature_upsample_res=256):
                 raise NotImplementedError("attention masks are never used on this path (ptp_utils.py:496)")
             batch_size, sequence_length, dim = x.shape
             is_cross = context is not None
-            q = self.to_q(x)
             ctx = context if is_cross else x
-            k = self.to_k(ctx)
-            v = self.to_v(ctx)
+            if (not is_cross) and self.to_q.bias is None and self.to_k.bias is None and self.to_v.bias is None \
+                    and "forward" not in self.to_q.__dict__:
+                q, k, v = ops.qkv_proj(x, self.to_q.weight, self.to_k.weight, self.to_v.weight)
+            else:
+                q = self.to_q(x)
+                k = self.to_k(ctx)
+                v = self.to_v(ctx)
             out = _attention_core(self, q, k, v, is_cross)
             if (is_cross and sequence_length <= MAX_STORED_SEQ
                     and len(controller.step_store["attn"]) < MAX_STORED_LAYERS):

@@ -636,3 +636,18 @@ def test_stride2_conv_with_input_gradient(ops, pad):
     (gx,) = torch.autograd.grad(y, x, dy)
     torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=2e-5)
     torch.testing.assert_close(gx.double(), gref, rtol=1e-4, atol=1e-4)
+
+
+def test_qkv_projection_backward_accumulates_in_gemm(ops):
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(2, 300, 64, generator=g).cuda().requires_grad_(True)
+    ws = [torch.randn(64, 64, generator=g).cuda() / 8 for _ in range(3)]
+    dys = [torch.randn(2, 300, 64, generator=g).cuda() for _ in range(3)]
+    q, k, v = ops.qkv_proj(x, *ws)
+    (gx,) = torch.autograd.grad([q, k, v], x, dys)
+    xd = x.detach().double().requires_grad_(True)
+    refs = [torch.nn.functional.linear(xd, w.double()) for w in ws]
+    (gr,) = torch.autograd.grad(refs, xd, [d.double() for d in dys])
+    for a, b in zip((q, k, v), refs):
+        torch.testing.assert_close(a.double(), b, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx.double(), gr, rtol=1e-5, atol=1e-5)
