@@ -280,3 +280,20 @@ def test_sd2x_sdxl_module_tree_contract():
     heads = {m.heads for n, m in sdxl.named_modules() if m.__class__.__name__ == "CrossAttention"}
     assert heads == {10, 20}
     assert tuple(ptp_utils.init_random_noise("cpu", 77, sdxl.config["cross_attention_dim"]).shape) == (1, 77, 2048)
+
+
+def test_linear_and_qkv_dispatch_rules_on_cpu():
+    """Host logic of the experiment switch and the projection helper: on CPU tensors both are the library ops."""
+    import torch
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 10, 64, generator=g, requires_grad=True)
+    ws = [torch.randn(64, 64, generator=g) for _ in range(3)]
+    b = torch.randn(64, generator=g)
+    assert not ops.linear_x3_supported(x, ws[0]) and not ops.linear_x3_wanted(x, ws[0])
+    assert torch.equal(ops.linear_auto(x, ws[0], b), torch.nn.functional.linear(x, ws[0], b))
+    q, k, v = ops.qkv_proj(x, *ws)
+    for a, w in zip((q, k, v), ws):
+        assert torch.equal(a, torch.nn.functional.linear(x, w))
+    y = ops.conv1x1_nobias(torch.randn(2, 8, 3, 5, generator=g), torch.randn(4, 8, 1, 1, generator=g))
+    assert y.shape == (2, 4, 3, 5)
