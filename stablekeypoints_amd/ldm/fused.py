@@ -77,6 +77,30 @@ def _transformer_forward(m: Transformer2DModel):
     return forward
 
 
+def _vae_attention_forward(m: AttentionBlock):
+    """VAE mid-block attention: GroupNorm on the fused kernel, tiled NCHW -> token transpose instead of a strided copy, the
+    way back fused with the residual add.  The d = 512 single-head core stays on the library GEMMs + softmax."""
+    orig = m.forward
+
+    def forward(x):
+        if not (ops.group_norm_supported(x, m.group_norm.num_groups) and ops.layout_supported(x)):
+            return orig(x)
+        b, c, hh, ww = x.shape
+        t = ops.nchw_to_tokens(ops.group_norm_silu(x, m.group_norm, silu=False))        # [b, hh*ww, c]
+        q, k, v = m.query(t), m.key(t), m.value(t)
+        nh = m.num_heads
+        d = c // nh
+
+        def split(u):
+            return u.reshape(b, -1, nh, d).permute(0, 2, 1, 3).reshape(b * nh, -1, d)
+        q, k, v = split(q), split(k), split(v)
+        attn = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device),
+                             q, k.transpose(1, 2), beta=0, alpha=1.0 / (d ** 0.5)).softmax(dim=-1)
+        o = torch.bmm(attn, v).reshape(b, nh, -1, d).permute(0, 2, 1, 3).reshape(b, -1, c)
+        return ops.tokens_to_nchw_add(m.proj_attn(o), x)
+    return forward
+
+
 def _conv_forward(m: torch.nn.Conv2d):
     def forward(x):
         return ops.conv3x3_auto(x, m.weight, m.bias)
@@ -115,6 +139,9 @@ def fuse_norms(module: torch.nn.Module) -> int:
                 and mod.padding == (1, 1) and mod.dilation == (1, 1) and mod.groups == 1
                 and mod.padding_mode == "zeros" and "forward" not in mod.__dict__):
             mod.forward = _conv_forward(mod)        # Upsample2D.conv and friends (resnet convs are called below)
+            continue
+        if isinstance(mod, AttentionBlock) and "forward" not in mod.__dict__:
+            mod.forward = _vae_attention_forward(mod); n += 1
             continue
         if isinstance(mod, ResnetBlock2D) and "forward" not in mod.__dict__:
             mod.forward = _resnet_forward(mod); n += 1
