@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -232,7 +233,8 @@ def measured_traffic(kernel_substr):
         except Exception:
             continue
         for name, c in k.items():
-            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            plain = re.sub(r"<[^<>]*>", "", name).replace("void ", "")          # template arguments / return type of the trace name
+            if kernel_substr in plain and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "profiles/" + os.path.basename(path)
     return None, None
 
