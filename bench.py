@@ -104,7 +104,7 @@ def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None):
 
     out = {}
     for name, fn in (("fwd", run_fwd), ("bwd", run_bwd)):
-        for _ in range(3):
+        for _ in range(10):                                      # warm clocks (the GPU idled while the inputs were drawn)
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
