@@ -96,3 +96,44 @@ def optimize_embedding_cpu(ldm, images, context, *, steps, batch_size, R_up, lr=
         opt.step()
         opt.zero_grad()
     return context.detach(), time.perf_counter() - t0, n_img
+
+
+def optimize_trajectory(ldm, images, context, order, noise, thetas, *, steps, accum, R_up, lr=5e-3, **kw):
+    """optimize.py:339-425 with the loader order and every random draw INJECTED (G11): `order` [steps*accum] image
+    indices, `noise` [2*steps*accum, 4,h,w] in draw order (image view, warped view, ...), `thetas` [steps*accum,2,3].
+    Returns the embedding after every optimizer step, [steps, T, C]."""
+    store = R.OracleStore()
+    register_reference_hook(ldm.unet, store, R_up)
+    context = context.clone().requires_grad_(True)
+    opt = torch.optim.Adam([context], lr=lr)
+    after = []
+    for it in range(steps * accum):
+        img = images[int(order[it])][None]
+        loss, *_ = image_step(ldm, img, context, store, thetas[it:it + 1], noise[2 * it:2 * it + 1],
+                              noise[2 * it + 1:2 * it + 2], **kw)
+        (loss / accum).backward()                               # optimize.py:418-420
+        if (it + 1) % accum == 0:                               # :421-423
+            opt.step()
+            opt.zero_grad()
+            after.append(context.detach().clone()[0])
+    return torch.stack(after)
+
+
+def find_best_indices(ldm, images, context, order, noise, *, R_up, furthest_point_num_samples, top_k, sigma,
+                      num_subjects=1, layers=(0, 1, 2, 3), with_scores=False):
+    """keypoint_regressor.py:56-108 with the loader order and the noise draws injected (G12): per image ONE untransformed
+    view -> candidates by KL -> furthest-point sampling on the SAME map -> vote.  -> (indices, per-image selections)."""
+    store = R.OracleStore()
+    register_reference_hook(ldm.unet, store, R_up)
+    picked, scores = [], []
+    with torch.no_grad():
+        for it, i in enumerate(order):
+            am = maps_for(ldm, images[int(i)][None], context, store, noise[it:it + 1], layers)
+            cand = R.find_top_k_gaussian(am, furthest_point_num_samples, sigma=sigma, num_subjects=num_subjects)
+            picked.append(R.furthest_point_sampling(am, top_k, cand))
+            if with_scores:
+                scores.append(R.gaussian_kl(am, sigma, num_subjects=num_subjects))
+    flat = torch.cat(picked)                                                                     # :100-101
+    indices, counts = torch.unique(flat, return_counts=True)                                     # :103
+    out = indices[counts.argsort(descending=True)][:top_k]                                       # :104-105
+    return (out, torch.stack(picked), torch.stack(scores)) if with_scores else (out, torch.stack(picked))

@@ -71,6 +71,13 @@ FULL_CASE = dict(layers=[(16, 1280), (16, 1280), (16, 1280), (32, 640)], heads=8
 TINY_CASE = dict(size=128, T=16, R=32, n_cand=8, top_k=4, sigma=2.0, seed=61, aug_iters=3, upscale=64)
 
 
+# G11/G12: the reference's optimize_embedding (3 optimizer steps x 2 accumulated images) and find_best_indices (24 images)
+# on the same reduced-width model; 6 seeded images behind a tensor-dataset stub.  `ctx_gain` scales the start embedding so
+# that the token softmax is clearly non-uniform and the KL ranking is not decided by rounding.
+LOOP_CASE = dict(size=128, T=16, R=32, n_cand=8, top_k=4, sigma=2.0, seed=81, n_images=6, steps=3, accum=2,
+                 num_indices=24, ctx_gain=1.0)
+
+
 def selection_maps():
     """Two [T,R,R] non-negative maps with sum_t == 1 per pixel, some peaky tokens, and an exact
     two-way tie (pins the first-index argmax rule)."""

@@ -57,18 +57,24 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
                                      augmentation_iterations=20, noise_level=-1, augment_degrees=30,
                                      augment_scale=(0.9, 1.1), augment_translate=(0.1, 0.1), visualize=False,
                                      controllers=None, num_gpus=1, save_folder="outputs", upscale_size=512,
-                                     thetas=None, noise=None):
+                                     thetas=None, noise=None, shard_over_ranks=False):
     """eval.py:197-355: maps of the selected tokens averaged over random affine views of ONE image.
 
     Reference loop: per augmentation -> UNet forward -> collect_maps(indices, upsample_res=upscale_size) ->
     inverse-warp the maps and a ones-mask -> accumulate; result = sum/count with NaN -> 0.
-    Here all of this rank's views go through the network as ONE batch (early exit, fused map kernel);
-    gather/resize/unwarp stay linear ops applied after the layer/head mean.
-    Multi-GPU: the augmentations are sharded over the ranks -- each rank runs
-    `augmentation_iterations // (num_gpus * world_size)` views -- and the un-warped sum and the coverage count
-    ([K,S,S] each) are all-reduced before the division, so every rank returns the same averaged maps.
-    `thetas` [n,2,3] / `noise` [n,4,h,w] let a caller inject THIS rank's random draws (parity tests)."""
+    Here all views go through the network as ONE batch (early exit, fused map kernel); gather / resize / unwarp
+    stay linear ops applied after the layer/head mean.  The view count is the reference's
+    `(augmentation_iterations // num_gpus) * num_gpus`.
+
+    By default every rank that calls this processes ALL views of ITS image (callers shard the images over ranks, as
+    `find_best_indices` / `optimize_embedding` do): no collective.  `shard_over_ranks=True` is for the
+    opposite layout -- every rank holds the SAME image: rank 0 draws all affine matrices and all noise and broadcasts
+    them, rank r takes views r, r+world, ... and the un-warped sum and the coverage count ([K,S,S] each) are
+    all-reduced before the division, so the ensemble is the same `n` views as on one GPU and every rank returns the
+    same averaged maps; a view count that does not divide by the world size raises.
+    `thetas` [n,2,3] / `noise` [n,4,h,w] inject the draws for ALL n views (parity tests)."""
     import numpy as np
+    from . import dist as skp_dist
     from . import ptp_utils
     from ._maps import collect_maps_batched
     from .invertable_transform import RandomAffineWithInverse
@@ -80,12 +86,26 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     if isinstance(image, np.ndarray):
         image = torch.from_numpy(image).permute(2, 0, 1)
     image = image.to(device=dev, dtype=torch.float32)
-    from . import dist as skp_dist
-    n = augmentation_iterations // (num_gpus * skp_dist.world_size())
+    n = (augmentation_iterations // num_gpus) * num_gpus
     if n < 1:
-        raise ValueError(f"augmentation_iterations ({augmentation_iterations}) is smaller than the data-parallel width")
+        raise ValueError(f"augmentation_iterations ({augmentation_iterations}) is smaller than num_gpus ({num_gpus})")
+    world = skp_dist.world_size() if shard_over_ranks else 1
+    if n % world:
+        raise ValueError(f"{n} augmented views do not divide over {world} ranks")
     tr = RandomAffineWithInverse(degrees=augment_degrees, scale=augment_scale, translate=augment_translate)
-    views = tr(image[None].repeat(n, 1, 1, 1), theta=thetas)
+    if thetas is None:
+        thetas = tr.sample_theta(n)                                # host RNG, 4 uniforms per view (invertable_transform.py:42-52)
+    thetas = torch.as_tensor(thetas, dtype=torch.float32)
+    if noise is None:
+        noise = torch.randn(n, 4, image.shape[-2] // 8, image.shape[-1] // 8, device=dev)
+    noise = noise.to(dev)
+    if world > 1:                                                  # one ensemble for the whole job: rank 0's draws
+        thetas, noise = thetas.to(dev).contiguous(), noise.contiguous()
+        skp_dist.broadcast_(thetas, 0)
+        skp_dist.broadcast_(noise, 0)
+        r = skp_dist.rank()
+        thetas, noise = thetas[r::world].cpu(), noise[r::world]
+    views = tr(image[None].repeat(thetas.shape[0], 1, 1, 1), theta=thetas)
     ptp_utils.find_pred_noise(ldm, views, context.to(dev), noise_level=noise_level, device=dev, noise=noise,
                               early_exit=True, controllers={dev: controller})
     maps = collect_maps_batched(controller, layers=layers)                  # [n,T,R,R]
@@ -93,14 +113,14 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     maps = F.interpolate(maps[:, idx], size=(upscale_size, upscale_size), mode="bilinear", align_corners=False)
     num = tr.inverse(torch.ones_like(maps)).sum(dim=0)
     tot = tr.inverse(maps).sum(dim=0)
-    return finish_augmented(tot, num)
+    return finish_augmented(tot, num, reduce=world > 1)
 
 
-def finish_augmented(tot, num):
-    """eval.py:343-353 across ranks: SUM all-reduce of the un-warped map sum and of the coverage count (one exchange of
-    2 x [K,S,S] floats), then sum / count with 0/0 -> 0."""
+def finish_augmented(tot, num, reduce=True):
+    """eval.py:343-353; with `reduce` across ranks: SUM all-reduce of the un-warped map sum and of the coverage count
+    (one exchange of 2 x [K,S,S] floats), then sum / count with 0/0 -> 0."""
     from . import dist as skp_dist
-    if skp_dist.world_size() > 1:
+    if reduce and skp_dist.world_size() > 1:
         both = torch.stack([tot, num])
         skp_dist.allreduce_sum_(both)
         tot, num = both[0], both[1]

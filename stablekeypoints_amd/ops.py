@@ -221,6 +221,10 @@ def token_stats(M: torch.Tensor, num_subjects: int = 1, sigma: float = 2.0, eps:
     return (am, kl, ent) if want_entropy else (am, kl)
 
 
+SELECT_MAX_CANDIDATES = 64     # SKP_SEL_MAXC / SKP_SEL_MAXT of csrc/skp_select_loss.hip
+SELECT_MAX_TOKENS = 1024
+
+
 def select_tokens(kl: torch.Tensor, argmax_t: torch.Tensor, R: int, n_cand: int, top_k: int):
     """-> (cand int64 [n_cand], sel int64 [top_k]); argmax_t = first-subject arg-max of the TRANSFORMED map."""
     T = kl.shape[0]

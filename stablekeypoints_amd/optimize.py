@@ -150,9 +150,13 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
 
 
 def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
-                       from_where=["down_cross", "mid_cross", "up_cross"]):
+                       from_where=["down_cross", "mid_cross", "up_cross"], draws=None, trajectory_out=None):
     """Reference signature (optimize.py:269-276).  `num_gpus` = devices driven by THIS process (1); the
-    data-parallel width is `num_gpus * world_size`.  Returns the detached embedding [1,T,768]."""
+    data-parallel width is `num_gpus * world_size`.  Returns the detached embedding [1,T,768].
+    `draws = (order, noise, thetas)` injects THIS rank's image order [steps*accum], the noise of every forward in the
+    reference's draw order ([2*steps*accum,4,h,w]: image view, warped view, next image ...) and the affine matrices
+    [steps*accum,2,3] (parity tests; the reference takes all three from the global RNGs, optimize.py:333-365);
+    `trajectory_out`, a list, receives the embedding after every optimizer step."""
     world, rank = skp_dist.world_size(), skp_dist.rank()
     width = num_gpus * world
     if args.batch_size < width or args.batch_size % width:
@@ -180,7 +184,12 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
         done = 0
         while done < accum:
             n = min(group, accum - done)
-            idx = []
+            idx, inject = [], {}
+            if draws is not None:
+                it = step * accum + done                         # this rank's iteration counter (optimize.py:339)
+                idx = [int(i) for i in draws[0][it:it + n]]
+                pair = torch.as_tensor(draws[1][2 * it:2 * (it + n)]).to(dev)
+                inject = dict(noise=torch.cat([pair[0::2], pair[1::2]]), thetas=torch.as_tensor(draws[2][it:it + n]))
             while len(idx) < n:                                  # epoch-wise shuffled, rank-sharded indices
                 if cursor >= len(order):
                     perm = torch.randperm(len(dataset), generator=shuffle_gen).tolist()
@@ -189,9 +198,12 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
                         raise ValueError("dataset smaller than the data-parallel width")
                 idx.append(order[cursor]); cursor += 1
             images = torch.stack([dataset[i]["img"] for i in idx])
-            running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size))
+            running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size,
+                                              **inject))
             done += n
         reducer.step()
+        if trajectory_out is not None:
+            trajectory_out.append(context.detach().clone())
         if log_every and (step + 1) % log_every == 0:
             skp_dist.allreduce_sum_(running)                     # every rank holds its share of the batch mean
         if log_every and (step + 1) % log_every == 0 and rank == 0:

@@ -89,11 +89,16 @@ MAX_STORED_SEQ = 32 ** 2       # ptp_utils.py:510
 def _attention_core(module, q, k, v, is_cross=False):
     """softmax(scale q k^T) v per head (ptp_utils.py:493-506) on [B,N,C]/[B,T,C] tensors.  Cross layers with
     a short key axis run on the fused fp32-MFMA kernel (csrc/skp_cross_attn.hip); self-attention runs on the
-    flash-style kernels (csrc/skp_self_attn.hip).  Unsupported head sizes keep the plain formulation."""
-    if is_cross and q.is_cuda and ops.cross_attn_supported(q.shape[-1], module.heads, k.shape[1]):
-        return ops.cross_attention(q, k, v, module.heads, module.scale)
-    if (not is_cross) and q.is_cuda and ops.self_attn_supported(q.shape[-1], module.heads):
-        return ops.self_attention(q, k, v, module.heads, module.scale)
+    flash-style kernels (csrc/skp_flash_attn.hip, csrc/skp_self_attn.hip).  On the GPU there is NO other route: a head
+    size without a kernel raises.  Host tensors (the module tree on CPU is what oracle/ drives) take the plain
+    baddbmm / softmax / bmm formulation of the reference."""
+    if q.is_cuda:
+        if is_cross and ops.cross_attn_supported(q.shape[-1], module.heads, k.shape[1]):
+            return ops.cross_attention(q, k, v, module.heads, module.scale)
+        if ops.self_attn_supported(q.shape[-1], module.heads):
+            return ops.self_attention(q, k, v, module.heads, module.scale)
+        raise RuntimeError(f"attention with {module.heads} heads of {q.shape[-1] // module.heads} channels has no HIP kernel "
+                           f"(built head sizes: {ops.CROSS_ATTN_HEAD_DIMS}); there is no eager fallback on the GPU")
     qh = module.reshape_heads_to_batch_dim(q)
     kh = module.reshape_heads_to_batch_dim(k)
     vh = module.reshape_heads_to_batch_dim(v)
@@ -246,34 +251,40 @@ def run_and_find_attn(ldm, image, context, noise_level=-1, device="cuda",
 # ---------------------------------------------------------------------------------------------
 # token selection                                              reference ptp_utils.py:86-159
 # ---------------------------------------------------------------------------------------------
+def _ranked(score, argmax, R, top_k):
+    """First `top_k` token ids by ascending score (ties by index, NaN last -- torch.argsort's order): the selection
+    kernel's ranking stage; candidate lists longer than the kernel's 64 slots are a stable device sort."""
+    n = score.shape[0]
+    top_k = min(int(top_k), n)
+    if 2 <= top_k <= ops.SELECT_MAX_CANDIDATES and n <= ops.SELECT_MAX_TOKENS:
+        cand, _ = ops.select_tokens(score, argmax, R, top_k, 2)
+        return cand
+    return torch.sort(score, stable=True).indices[:top_k]
+
+
 def find_top_k_gaussian(attention_maps, top_k, sigma=3, epsilon=1e-5, num_subjects=1):
     """ptp_utils.py:86-112 -> int64[top_k] (device)."""
     am, kl = ops.token_stats(attention_maps, num_subjects=num_subjects, sigma=sigma, eps=epsilon)
-    n = attention_maps.shape[0]
-    top_k = min(int(top_k), n)
-    cand, _ = ops.select_tokens(kl, am[0], attention_maps.shape[-1], max(top_k, 2), 2)
-    return cand[:top_k]
+    return _ranked(kl, am[0], attention_maps.shape[-1], top_k)
 
 
 def furthest_point_sampling(attention_maps, top_k, top_initial_candidates):
-    """ptp_utils.py:115-159 -> int64[top_k] (device); greedy max-min over the candidates' arg-max pixels."""
+    """ptp_utils.py:115-159 -> int64[min(top_k, candidates)] (device); greedy max-min over the candidates' arg-max
+    pixels (the reference's loop stops adding once every candidate is chosen, :142-157)."""
     am, _ = ops.token_stats(attention_maps, num_subjects=1, want_kl=False)
     n = attention_maps.shape[0]
     cand = torch.as_tensor(top_initial_candidates, device=attention_maps.device).long()
     order = torch.full((n,), float("inf"), device=attention_maps.device)
     order[cand] = torch.arange(cand.numel(), device=attention_maps.device, dtype=torch.float32)
-    _, sel = ops.select_tokens(order, am[0], attention_maps.shape[-1], int(cand.numel()), int(top_k))
+    _, sel = ops.select_tokens(order, am[0], attention_maps.shape[-1], int(cand.numel()),
+                               min(int(top_k), int(cand.numel())))
     return sel
 
 
 def entropy_sort(attention_maps, top_k, min_dist=0.05):
     """ptp_utils.py:165-187 -> int64[top_k] (device): tokens by ascending entropy of softmax_{R*R}(map)."""
-    _, _, ent = ops.token_stats(attention_maps, num_subjects=1, want_kl=False, want_entropy=True)
-    n = attention_maps.shape[0]
-    top_k = min(int(top_k), n)
-    am = torch.zeros(n, device=attention_maps.device, dtype=torch.int32)
-    cand, _ = ops.select_tokens(ent, am, attention_maps.shape[-1], max(top_k, 2), 2)
-    return cand[:top_k]
+    am, _, ent = ops.token_stats(attention_maps, num_subjects=1, want_kl=False, want_entropy=True)
+    return _ranked(ent, am[0], attention_maps.shape[-1], top_k)
 
 
 def init_random_noise(device, num_words=77, dim=768):

@@ -238,3 +238,46 @@ def test_g8_oracle_full_step_vs_reference_driver(golden):
     loss.backward()
     ref = t(g["context_grad"])
     torch.testing.assert_close(ctx.grad, ref, rtol=1e-3, atol=1e-5 * ref.abs().max().item())
+
+
+def _loop_inputs():
+    from oracle.fixtures import LOOP_CASE as lc
+    images = torch.rand(lc["n_images"], 3, lc["size"], lc["size"], generator=torch.Generator().manual_seed(lc["seed"]))
+    ctx0 = seeded((1, lc["T"], 768), lc["seed"] + 1) * lc["ctx_gain"]
+    return lc, images, ctx0
+
+
+def test_g11_oracle_trajectory_vs_reference_optimize_embedding(golden):
+    """oracle/cpu_path.optimize_trajectory against the REFERENCE's own `optimize.optimize_embedding` loop
+    (optimize.py:269-452: 3 optimizer steps x 2 accumulated images, Adam) on the reduced-width model, fed the loader
+    order / noise / thetas the reference drew (G11): the embedding after every optimizer step."""
+    from oracle import cpu_path
+    from stablekeypoints_amd.optimize_token import load_ldm
+    g = golden("g11_reference_trajectory_tiny.npz")
+    lc, images, ctx0 = _loop_inputs()
+    ldm, _, _ = load_ldm("cpu", "tiny", feature_upsample_res=lc["R"])
+    traj = cpu_path.optimize_trajectory(ldm, images, ctx0, g["order"], t(g["noise"]), t(g["thetas"]), steps=lc["steps"],
+                                        accum=lc["accum"], R_up=lc["R"], furthest_point_num_samples=lc["n_cand"],
+                                        top_k=lc["top_k"], sigma=lc["sigma"])
+    ref = t(g["context"])
+    assert ref.shape == (lc["steps"], lc["T"], 768)
+    torch.testing.assert_close(traj, ref, rtol=1e-5, atol=1e-6)
+    # every step moved the embedding by about lr (Adam's first steps are sign-like), cumulatively
+    assert 0.9 * 5e-3 < (ref[0] - ctx0[0]).abs().max().item() < 1.1 * 5e-3
+    assert (ref[2] - ctx0[0]).abs().max().item() > 2.5 * 5e-3
+
+
+def test_g12_oracle_best_indices_vs_reference_find_best_indices(golden):
+    """oracle/cpu_path.find_best_indices against the REFERENCE's own `keypoint_regressor.find_best_indices` (:16-108)
+    over 24 images (G12): per-image selections and the voted indices, exact."""
+    from oracle import cpu_path
+    from stablekeypoints_amd.optimize_token import load_ldm
+    g11, g = golden("g11_reference_trajectory_tiny.npz"), golden("g12_reference_best_indices_tiny.npz")
+    lc, images, _ = _loop_inputs()
+    ldm, _, _ = load_ldm("cpu", "tiny", feature_upsample_res=lc["R"])
+    out, picked = cpu_path.find_best_indices(ldm, images, t(g11["context"])[-1][None], g["order"], t(g["noise"]),
+                                             R_up=lc["R"], furthest_point_num_samples=lc["n_cand"], top_k=lc["top_k"],
+                                             sigma=lc["sigma"])
+    assert len(g["order"]) == lc["num_indices"] == 24
+    assert torch.equal(picked, t(g["per_image"]))
+    assert torch.equal(out, t(g["indices"]))

@@ -1,0 +1,221 @@
+"""GPU parity added in round 3: the reference's OWN loops as goldens -- `optimize_embedding` trajectory (G11) and
+`find_best_indices` vote (G12) -- through the product's entry points; `find_best_indices` at the reference default
+`--num_indices 100`; one full-width SD-1.5 step against the oracle's reference-order CPU step; the GPU attention core
+refuses head sizes without a kernel; rank-sharding of the augmented inference is opt-in."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_path as R
+from oracle.fixtures import LOOP_CASE as lc, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _loop_inputs():
+    images = torch.rand(lc["n_images"], 3, lc["size"], lc["size"], generator=torch.Generator().manual_seed(lc["seed"]))
+    ctx0 = seeded((1, lc["T"], 768), lc["seed"] + 1) * lc["ctx_gain"]
+    return images, ctx0
+
+
+class _TensorImages(torch.utils.data.Dataset):
+    def __init__(self, data):
+        self.data = data
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, i):
+        return {"img": self.data[i]}
+
+
+def _loop_args(**over):
+    from stablekeypoints_amd.optimize import default_args
+    return default_args(num_tokens=lc["T"], feature_upsample_res=lc["R"], furthest_point_num_samples=lc["n_cand"],
+                        top_k=lc["top_k"], sigma=lc["sigma"], batch_size=lc["accum"], num_steps=lc["steps"],
+                        image_size=lc["size"], device="cuda", log_interval=0, num_indices=lc["num_indices"], **over)
+
+
+@pytest.fixture()
+def tiny(monkeypatch):
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from stablekeypoints_amd import keypoint_regressor, optimize
+    from stablekeypoints_amd.optimize_token import load_ldm
+    images, ctx0 = _loop_inputs()
+    ds = _TensorImages(images.cuda())
+    monkeypatch.setattr(optimize, "build_dataset", lambda args: ds)
+    monkeypatch.setattr(keypoint_regressor, "build_dataset", lambda args: ds)
+    ldm, controllers, n = load_ldm("cuda", "tiny", feature_upsample_res=lc["R"])
+    return ldm, controllers, n, images, ctx0
+
+
+@pytest.mark.parametrize("images_per_forward", [2, 1])
+def test_g11_optimize_embedding_trajectory_vs_reference(tiny, golden, images_per_forward):
+    """The product's `optimize_embedding` (batched fused steps, HIP kernels, Adam) fed the loader order / noise / thetas
+    of the REFERENCE's own `optimize_embedding` run (G11: 3 optimizer steps x 2 accumulated images): the embedding
+    after every optimizer step.  Tolerances: embedding rtol 5e-3 (stated bar) AND -- because that alone is loose
+    against steps of lr = 5e-3 on unit-scale values -- the DISPLACEMENT from the start embedding: mean error below
+    2 % of lr, and fewer than 0.5 % of the elements off by more than a quarter step (Adam's first updates are
+    sign(g)*lr, so an element whose accumulated gradient is at rounding level may legitimately flip)."""
+    from stablekeypoints_amd.optimize import optimize_embedding
+    ldm, controllers, n, images, ctx0 = tiny
+    g = golden("g11_reference_trajectory_tiny.npz")
+    traj = []
+    out = optimize_embedding(ldm, _loop_args(images_per_forward=images_per_forward), controllers, n, context=ctx0.clone(),
+                             draws=(g["order"], t(g["noise"]), t(g["thetas"])), trajectory_out=traj)
+    ref = t(g["context"])
+    got = torch.cat(traj).cpu()
+    assert got.shape == ref.shape and torch.equal(out.cpu()[0], got[-1])
+    torch.testing.assert_close(got, ref, rtol=5e-3, atol=1e-5)
+    lr = 5e-3
+    for s in range(lc["steps"]):
+        err = ((got[s] - ctx0[0]) - (ref[s] - ctx0[0])).abs()
+        print(f"step {s + 1}: displacement error mean {err.mean().item() / lr:.4f} lr, max {err.max().item() / lr:.3f} lr, "
+              f"elements > lr/4: {(err > lr / 4).float().mean().item():.5f}")
+        assert err.mean().item() < 0.02 * lr
+        assert (err > lr / 4).float().mean().item() < 5e-3
+    assert (got[-1] - ctx0[0]).abs().max().item() > 2.5 * lr
+
+
+def _oracle_votes(images, ctx, order, noise):
+    from oracle import cpu_path
+    from stablekeypoints_amd.optimize_token import load_ldm
+    cpu, _, _ = load_ldm("cpu", "tiny", feature_upsample_res=lc["R"])
+    return cpu_path.find_best_indices(cpu, images, ctx, order, noise, R_up=lc["R"], furthest_point_num_samples=lc["n_cand"],
+                                      top_k=lc["top_k"], sigma=lc["sigma"], with_scores=True)
+
+
+def _check_votes(picked, ref_picked, kl_ref):
+    """Per-image selections must be the reference's, in order.  The only licence: the candidate cut (rank n_cand vs
+    n_cand + 1) or the order of two candidates hinges on KL scores that agree to 1e-4 relative -- the fp32 rounding of
+    two different summation orders -- in which case that image is reported and skipped (test_round2_gpu.py states the
+    same rule).  Returns the number of exact images."""
+    exact = 0
+    for i in range(ref_picked.shape[0]):
+        if torch.equal(picked[i], ref_picked[i]):
+            exact += 1
+            continue
+        s, _ = kl_ref[i].sort()
+        gaps = (s[1:lc["n_cand"] + 1] - s[:lc["n_cand"]]) / s[:lc["n_cand"]].abs()
+        assert gaps.min().item() < 1e-4, f"image {i}: selection differs although every score gap is decisive"
+        print(f"image {i}: near-tie (min relative KL gap {gaps.min().item():.2e}); selection {picked[i].tolist()} vs "
+              f"reference {ref_picked[i].tolist()}")
+    return exact
+
+
+def test_g12_find_best_indices_vs_reference(tiny, golden):
+    """The product's `find_best_indices` (three forwards of eight images) fed the loader order and noise of the
+    REFERENCE's own `keypoint_regressor.find_best_indices` run over 24 images (G12), with the embedding the reference's
+    optimisation ended on (G11): per-image selections (order included) and the voted indices, bit-exact."""
+    from stablekeypoints_amd.keypoint_regressor import find_best_indices
+    ldm, controllers, n, images, _ = tiny
+    g11, g = golden("g11_reference_trajectory_tiny.npz"), golden("g12_reference_best_indices_tiny.npz")
+    ctx = t(g11["context"])[-1][None]
+    votes = []
+    idx = find_best_indices(ldm, ctx.cuda(), _loop_args(), controllers, n, draws=(g["order"], t(g["noise"])),
+                            votes_out=votes)
+    ref_picked = t(g["per_image"])
+    assert votes[0].shape == ref_picked.shape == (24, lc["top_k"])
+    if not torch.equal(votes[0], ref_picked):
+        _, _, kl = _oracle_votes(images, ctx, g["order"], t(g["noise"]))
+        exact = _check_votes(votes[0], ref_picked, kl)
+        assert exact >= 21, "more than three of 24 images hit a near-tie: the scores are not the reference's"
+        pytest.xfail("per-image selections differ on documented near-ties only; the vote is not comparable")
+    assert idx.dtype == torch.int64 and torch.equal(idx, t(g["indices"]))
+
+
+def test_find_best_indices_reference_default_num_indices(tiny):
+    """`--num_indices 100` (the reference default, main.py): 13 forwards of <= 8 images over a 6-image dataset that is
+    reshuffled every epoch; also top_k above the candidate count (the greedy loop returns min(top_k, candidates))."""
+    from stablekeypoints_amd.keypoint_regressor import find_best_indices
+    ldm, controllers, n, images, ctx0 = tiny
+    votes = []
+    idx = find_best_indices(ldm, ctx0.cuda(), _loop_args(num_indices=100), controllers, n, votes_out=votes)
+    assert votes[0].shape == (100, lc["top_k"]) and idx.shape == (lc["top_k"],) and len(set(idx.tolist())) == lc["top_k"]
+    flat, counts = torch.unique(votes[0].flatten(), return_counts=True)
+    assert torch.equal(idx, flat[counts.argsort(descending=True)][:lc["top_k"]])
+    assert all(len(set(v.tolist())) == lc["top_k"] for v in votes[0])
+    votes = []
+    idx = find_best_indices(ldm, ctx0.cuda(), _loop_args(num_indices=10, top_k=12), controllers, n, votes_out=votes)
+    assert votes[0].shape == (10, lc["n_cand"]) and idx.numel() <= 12
+
+
+def test_gpu_attention_core_refuses_unbuilt_head_size():
+    """No silent baddbmm / softmax / bmm route on the GPU: a head size without a HIP kernel raises."""
+    from stablekeypoints_amd import ptp_utils
+    from stablekeypoints_amd.ldm.attention import CrossAttention
+    mod = CrossAttention(48, 24, heads=4).cuda()                 # 12-channel heads: not built
+    q = torch.randn(1, 16, 48, device="cuda")
+    kv = torch.randn(1, 5, 48, device="cuda")
+    for is_cross in (True, False):
+        with pytest.raises(RuntimeError, match="no HIP kernel"):
+            ptp_utils._attention_core(mod, q, kv, kv, is_cross)
+    out = ptp_utils._attention_core(mod.cpu(), q.cpu(), kv.cpu(), kv.cpu(), True)     # host tensors: the plain formulation
+    assert out.shape == (1, 16, 48)
+
+
+def test_sd15_full_width_step_vs_oracle():
+    """FULL-WIDTH SD-1.5 (859.5 M-parameter UNet + VAE encoder, CPU-drawn weights on both sides), one image at 256^2
+    (BASELINE configs[0]'s shape), T = 77, R = 128: the product's fused `group_step` on the MI355X against the oracle's
+    reference-order CPU step (`oracle/cpu_path.image_step`: materialised attention, x-upsample + second to_q, stack+mean
+    collect_maps, python selection, torch losses, autograd).  Maps rtol 1e-3 (north_star), selected tokens exact or the
+    stated near-tie rule, losses 1e-3 / 2e-3, embedding gradient rtol 5e-3."""
+    from oracle import cpu_path
+    from stablekeypoints_amd import ptp_utils
+    from stablekeypoints_amd._maps import collect_maps_batched
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import default_args, group_step, image_losses
+    from stablekeypoints_amd.optimize_token import load_ldm
+    assert torch.cuda.is_available()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    Rup, T, n_cand, top_k = 128, 77, 25, 10
+    ldm, controllers, _ = load_ldm("cuda", "sd15", feature_upsample_res=Rup)
+    cpu, _, _ = load_ldm("cpu", "sd15", feature_upsample_res=Rup)
+    p_gpu, p_cpu = next(ldm.unet.parameters()), next(cpu.unet.parameters())
+    assert torch.equal(p_gpu.detach().cpu(), p_cpu.detach())     # same seeded weights on both sides
+    g = torch.Generator().manual_seed(5)
+    image = torch.rand(1, 3, 256, 256, generator=g)
+    # scaled so the token softmax is clearly non-uniform while the random-weight network stays well conditioned
+    # (tests/test_e2e_gpu.py::test_sd_shapes_maps_with_winograd_convs_match_library_convs)
+    ctx = torch.randn(1, T, 768, generator=g) * 5.0
+    noise = torch.randn(2, 4, 32, 32, generator=g)
+    theta = R.affine_matrix(9.0, 0.9, (0.1, -0.15))
+    args = default_args(num_tokens=T, feature_upsample_res=Rup, furthest_point_num_samples=n_cand, top_k=top_k, batch_size=1)
+    store = R.OracleStore()
+    assert cpu_path.register_reference_hook(cpu.unet, store, Rup) == 18
+    c_ref = ctx.clone().requires_grad_(True)
+    loss, sharp, equiv, sel, am, am_t = cpu_path.image_step(cpu, image, c_ref, store, theta, noise[0:1], noise[1:2],
+                                                            furthest_point_num_samples=n_cand, top_k=top_k, sigma=args.sigma)
+    loss.backward()
+    am, am_t = am.detach(), am_t.detach()
+    assert am.shape == (T, Rup, Rup) and am.max() > 2.5 * am.mean()
+    dev, controller = next(iter(controllers.items()))
+    tr = RandomAffineWithInverse()
+    with torch.no_grad():
+        both = torch.cat([image.cuda(), tr(image.cuda(), theta=theta)])
+        ptp_utils.find_pred_noise(ldm, both, ctx.cuda(), device=dev, noise=noise.cuda(), early_exit=True,
+                                  controllers=controllers)
+        assert [tuple(r.q.shape[1:]) for r in controller.step_store["attn"]] == [(64, 1280)] * 3 + [(256, 640)]
+        maps = collect_maps_batched(controller)
+    print("full-width maps: max rel diff", ((maps[0].cpu() - am).abs() / am.abs().clamp_min(1e-6)).max().item())
+    torch.testing.assert_close(maps[0].cpu(), am, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(maps[1].cpu(), am_t, rtol=1e-3, atol=1e-6)
+    _, _, sel_g = image_losses(maps[0], maps[1], theta.reshape(-1).tolist(), args)
+    if not torch.equal(sel_g.cpu(), sel):
+        kl = R.gaussian_kl(am, args.sigma)
+        s, _ = kl.sort()
+        gaps = (s[1:n_cand + 1] - s[:n_cand]) / s[:n_cand].abs()
+        assert gaps.min().item() < 1e-4, "selection differs although every score gap is decisive"
+        assert len(set(sel_g.tolist()) & set(sel.tolist())) >= top_k - 2
+        pytest.skip(f"near-tie in the KL ranking (min gap {gaps.min().item():.2e}): losses / gradient are not comparable")
+    c_gpu = ctx.clone().cuda().requires_grad_(True)
+    loss_g, eq_g, sh_g = group_step(ldm, image, c_gpu, args, controller, tr, denom=1, noise=noise.cuda(), thetas=theta)
+    assert abs(sh_g.item() - sharp.item()) < 1e-3 * abs(sharp.item())
+    assert abs(eq_g.item() - equiv.item()) < 2e-3 * abs(equiv.item())
+    gref = c_ref.grad
+    print("full-width grad: |g|max", gref.abs().max().item(), "max abs diff", (c_gpu.grad.cpu() - gref).abs().max().item())
+    torch.testing.assert_close(c_gpu.grad.cpu(), gref, rtol=5e-3, atol=5e-5 * gref.abs().max().item())
