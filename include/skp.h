@@ -97,6 +97,19 @@ int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[h
                          const int* s /*[host]*/, int L, int B, int H, int T, int R,
                          const float* dM, const float* lse, float* workspace, void* stream);
 
+/* Backward of the fused map for a SPARSE map gradient: the losses of optimize.py:157-206 index the map with the K
+ * selected tokens (optimize.py:395-414), so dM is non-zero on K rows per batch row only.
+ *   sel: [B,K] int64 token ids (distinct per row), G: [B,K,R,R] = those rows of dM (NOT divided by L*H),
+ *   lse: [B,L*H,R*R] from the forward.  dS[l] (layout of S[l], row stride ldt >= 16*ceil(T/16); natural-log domain) is
+ *   WRITTEN: every row, columns t < 16*ceil(T/16), pad columns = 0.  Any T (no token groups).
+ * Token-major sweep (csrc/skp_attn_map_tok.hip): no atomics, fixed summation order => bit-reproducible.
+ * Limits: s[l] <= 32, K <= 32, R <= 1024 (SKP_E_RANGE otherwise: use skp_attn_map_bwd_f32 with the dense dM).
+ * workspace: skp_attn_map_bwd_sparse_workspace() bytes. */
+int64_t skp_attn_map_bwd_sparse_workspace(const int* s /*[host]*/, int L, int B, int H, int T, int R, int K);
+int skp_attn_map_bwd_sparse_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/,
+                                int L, int B, int H, int T, int R, const int64_t* sel, const float* G, int K,
+                                const float* lse, void* workspace, int ldt, void* stream);
+
 /* Ordinary cross-attention core (ptp_utils.py:493-506,540) for a short key axis, fp32 MFMA, K/V staged in
  * LDS, softmax over the tokens in registers:
  *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]

@@ -122,6 +122,43 @@ def _map_bwd(S, dS, sides, B, H, T, R, dM, lse):
         launch(t0, t1, 2, dot)
 
 
+# Which map backward the fused step takes.  "auto": the sparse token-major sweep when T > 128 (one pass instead of token
+# groups x two passes: 2.9 vs 7.9 ms at T = 500, B = 8), the dense-gradient kernels for T <= 128 (0.54 vs 0.72 ms at
+# T = 77: there the sweep has too few token groups to fill the chip without 8-row bands; profiles/r03_map_kernels.md);
+# "sparse" / "dense" force one of them (A/B runs, tests).
+MAP_BWD_MODE = os.environ.get("SKP_MAP_BWD", "auto")
+MAP_SPARSE_MAX_SIDE, MAP_SPARSE_MAX_K, MAP_SPARSE_MAX_R = 32, 32, 1024     # limits of csrc/skp_attn_map_tok.hip
+
+
+def map_bwd_sparse_supported(sides, K: int, R: int, T: int = 10 ** 9) -> bool:
+    if MAP_BWD_MODE == "dense" or (MAP_BWD_MODE == "auto" and T <= TOKEN_GROUP):
+        return False
+    return max(sides) <= MAP_SPARSE_MAX_SIDE and 1 <= K <= MAP_SPARSE_MAX_K and R <= MAP_SPARSE_MAX_R
+
+
+def _map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse):
+    """dS[l] for a map gradient that is non-zero on the rows sel[b,:] of batch row b only (G [B,K,R,R] = those rows):
+    token-major sweep, any T, no token groups, no dV staging (csrc/skp_attn_map_tok.hip)."""
+    L, ldt, K = len(S), S[0].shape[-1], sel.shape[1]
+    sel = sel.to(torch.int64).contiguous()
+    G = _dev(G, "G")
+    dS = [torch.empty_like(s_) for s_ in S]
+    si, _k0 = N.int_array(sides)
+    lib = N.lib()
+    nbytes = lib.skp_attn_map_bwd_sparse_workspace(si, L, B, H, T, R, K)
+    if nbytes < 0:
+        N.check(int(nbytes), "skp_attn_map_bwd_sparse_workspace")
+    ws = torch.empty((nbytes + 3) // 4, device=G.device, dtype=torch.float32)
+    sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
+    dp, _k2 = N.ptr_array([t.data_ptr() for t in dS])
+    N.check(lib.skp_attn_map_bwd_sparse_f32(sp, dp, si, L, B, H, T, R, sel.data_ptr(), G.data_ptr(), K, lse.data_ptr(),
+                                            ws.data_ptr(), ldt, _stream()), "skp_attn_map_bwd_sparse_f32")
+    if ldt > (T + 15) // 16 * 16:                              # gap columns of a wider logits buffer: never read, keep finite
+        for d_ in dS:
+            d_[..., (T + 15) // 16 * 16:] = 0
+    return dS
+
+
 class AttnMapFn(torch.autograd.Function):
     """M[b,t,:,:] = mean over (layer, head) of softmax_t(bicubic_R(scale * q_l k_l^T)).
 
@@ -157,26 +194,32 @@ class AttnMapFn(torch.autograd.Function):
         # (never read) gap columns when T > 128 is not a multiple of 16
         dS = [torch.empty_like(s_) if T <= TOKEN_GROUP else torch.zeros_like(s_) for s_ in S]
         _map_bwd(S, dS, sides, B, H, T, R, dM, lse)
-        grads: List[torch.Tensor] = []
-        for l in range(L):
-            q, k, ds, sc = qs[l], ks[l], dS[l], scales[l]
-            s2, C = q.shape[1], q.shape[2]
-            d = C // H
-            Bk = k.shape[0]
-            NT = ds.shape[-1]
-            dq = dk = None
-            if ctx.needs_input_grad[3 + 2 * l]:
-                dq = torch.empty_like(q)       # dq[b,p,h*d+c] = sc * sum_t dS[b,h,p,t] k[bk,t,h*d+c]
-                _gemm_nt(ds, k, dq, s2, d, T, B, H,
-                         (H * s2 * NT, s2 * NT, NT, 1), (0 if Bk == 1 else T * C, d, 1, C),
-                         (s2 * C, d, C), sc)
-            if ctx.needs_input_grad[4 + 2 * l]:
-                dkb = torch.empty(B, T, C, device=q.device, dtype=torch.float32)
-                _gemm_nt(ds, q, dkb, T, d, s2, B, H,    # dk[b,t,h*d+c] = sc * sum_p dS[b,h,p,t] q[b,p,h*d+c]
-                         (H * s2 * NT, s2 * NT, 1, NT), (s2 * C, d, 1, C), (T * C, d, C), sc)
-                dk = dkb.sum(dim=0, keepdim=True) if (Bk == 1 and B > 1) else dkb
-            grads += [dq, dk]
-        return (None, None, None, *grads)
+        return (None, None, None, *_dqk_from_dS(qs, ks, dS, scales, H, T, ctx.needs_input_grad[3:]))
+
+
+def _dqk_from_dS(qs, ks, dS, scales, H: int, T: int, needs) -> List[torch.Tensor]:
+    """dq_l = scale * dS_l k_l, dk_l = scale * dS_l^T q_l on the fp32-MFMA GEMM (deterministic; a shared k sums over the
+    batch rows).  `needs[2l]`, `needs[2l+1]`: which gradients autograd asked for."""
+    grads: List[torch.Tensor] = []
+    for l in range(len(qs)):
+        q, k, ds, sc = qs[l], ks[l], dS[l], scales[l]
+        B, s2, C = q.shape
+        d = C // H
+        Bk = k.shape[0]
+        NT = ds.shape[-1]
+        dq = dk = None
+        if needs[2 * l]:
+            dq = torch.empty_like(q)       # dq[b,p,h*d+c] = sc * sum_t dS[b,h,p,t] k[bk,t,h*d+c]
+            _gemm_nt(ds, k, dq, s2, d, T, B, H,
+                     (H * s2 * NT, s2 * NT, NT, 1), (0 if Bk == 1 else T * C, d, 1, C),
+                     (s2 * C, d, C), sc)
+        if needs[2 * l + 1]:
+            dkb = torch.empty(B, T, C, device=q.device, dtype=torch.float32)
+            _gemm_nt(ds, q, dkb, T, d, s2, B, H,    # dk[b,t,h*d+c] = sc * sum_p dS[b,h,p,t] q[b,p,h*d+c]
+                     (H * s2 * NT, s2 * NT, 1, NT), (s2 * C, d, 1, C), (T * C, d, C), sc)
+            dk = dkb.sum(dim=0, keepdim=True) if (Bk == 1 and B > 1) else dkb
+        grads += [dq, dk]
+    return grads
 
 
 def attn_map(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], heads: int, scales: Sequence[float],
@@ -292,6 +335,66 @@ class LossesFn(torch.autograd.Function):
 def fused_losses(M, Mt, sel, argmax, theta, sigma: float, num_subjects: int = 1):
     """theta: the FORWARD 2x3 affine of this image (6 floats, row-major). -> (sharp, equiv)."""
     return LossesFn.apply(M, Mt, sel, argmax, invert_affine(theta), float(sigma), int(num_subjects))
+
+
+class MapLossesFn(torch.autograd.Function):
+    """One node for `maps -> selection -> losses` of a group of images (optimize.py:347-414 for n images x 2 views), so that
+    the map backward sees the gradient as it is -- K selected rows per batch row -- instead of a dense [B,T,R,R] tensor:
+        forward : logits -> fused maps (+ lse) -> per image: token scores, selection, both losses and their unit gradients
+        backward: G = go_sharp * g_sharp + go_equiv * g_eq (K rows per batch row) -> sparse token-major map backward
+                  (csrc/skp_attn_map_tok.hip) -> dq_l, dk_l on the fp32-MFMA GEMM.
+    apply(meta, q_0, k_0, q_1, k_1, ...) with rows 0..n-1 = the images, n..2n-1 = their affine copies;
+    meta = dict(R, heads, scales, thetas [n][6], sigma, num_subjects, strategy, n_cand, top_k, score_fn).
+    Returns (sum_i sharp_i, sum_i equiv_i, sel [n,K] int64)."""
+
+    @staticmethod
+    def forward(ctx, meta, *qk: torch.Tensor):
+        L = len(qk) // 2
+        qs = [_dev(qk[2 * i], "q") for i in range(L)]
+        ks = [_dev(qk[2 * i + 1], "k") for i in range(L)]
+        R, H, scales = int(meta["R"]), int(meta["heads"]), tuple(float(v) for v in meta["scales"])
+        B, T = qs[0].shape[0], ks[0].shape[1]
+        n = B // 2
+        sides = [int(round(q.shape[1] ** 0.5)) for q in qs]
+        S = [qk_logits(q, k, H, sc) for q, k, sc in zip(qs, ks, scales)]
+        M, lse = _map_fwd(S, sides, B, H, T, R)
+        sigma, ns = float(meta["sigma"]), int(meta["num_subjects"])
+        n_cand = min(int(meta["n_cand"]), T)
+        K = min(int(meta["top_k"]), n_cand)
+        dev = M.device
+        sel_all = torch.empty(n, K, device=dev, dtype=torch.int64)
+        g_sharp = torch.empty(n, K, R, R, device=dev, dtype=torch.float32)
+        g_eq_a, g_eq_b = torch.empty_like(g_sharp), torch.empty_like(g_sharp)
+        nchunk = (R * R + 1023) // 1024
+        partial = torch.empty(n, 2, K, nchunk, device=dev, dtype=torch.float32)
+        lib, st = N.lib(), _stream()
+        for i in range(n):
+            am, score = meta["score_fn"](M[i], meta["strategy"], ns, sigma)
+            am_t, _ = token_stats(M[n + i], num_subjects=1, sigma=sigma, want_kl=False)
+            N.check(lib.skp_select_tokens(score.data_ptr(), am_t.data_ptr(), T, R, n_cand, K, torch.empty(
+                n_cand, device=dev, dtype=torch.int64).data_ptr(), sel_all[i].data_ptr(), st), "skp_select_tokens")
+            th, _keep = N.float_array(invert_affine(meta["thetas"][i]))
+            N.check(lib.skp_losses_fwd_f32(M[i].data_ptr(), M[n + i].data_ptr(), sel_all[i].data_ptr(), K, T, R,
+                                           am.data_ptr(), ns, sigma, th, partial[i].data_ptr(), g_sharp[i].data_ptr(),
+                                           g_eq_a[i].data_ptr(), g_eq_b[i].data_ptr(), st), "skp_losses_fwd_f32")
+        sums = partial.sum(dim=(0, 2, 3)) / float(K * R * R)
+        ctx.save_for_backward(lse, sel_all, g_sharp, g_eq_a, g_eq_b, *qs, *ks, *S)
+        ctx.meta = (R, H, scales, tuple(sides), B, T, L)
+        ctx.mark_non_differentiable(sel_all)
+        return sums[0], sums[1], sel_all
+
+    @staticmethod
+    def backward(ctx, go_sharp, go_equiv, _go_sel):
+        R, H, scales, sides, B, T, L = ctx.meta
+        saved = ctx.saved_tensors
+        lse, sel_all, g_sharp, g_eq_a, g_eq_b = saved[:5]
+        qs, ks, S = saved[5:5 + L], saved[5 + L:5 + 2 * L], saved[5 + 2 * L:]
+        z = torch.zeros((), device=lse.device)
+        gs = z if go_sharp is None else go_sharp.reshape(()).float()
+        ge = z if go_equiv is None else go_equiv.reshape(()).float()
+        G = torch.cat([gs * g_sharp + ge * g_eq_a, ge * g_eq_b], dim=0)            # [B,K,R,R]
+        dS = _map_bwd_sparse(S, sides, B, H, T, R, torch.cat([sel_all, sel_all], dim=0), G, lse)
+        return (None, *_dqk_from_dS(qs, ks, dS, scales, H, T, ctx.needs_input_grad[1:]))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -123,6 +123,39 @@ def token_order(attn_map, strategy, num_subjects, sigma):
     raise NotImplementedError(strategy)
 
 
+def _group_losses(controller, thetas, args, n):
+    """(sum_i equiv_i, sum_i sharp_i) of the 2n stored rows.  Default: ONE autograd node from the hooked layers' q / k to
+    the two loss sums (ops.MapLossesFn), whose backward hands the map kernels the gradient as K selected rows per batch
+    row -- taken where it is the faster one (T > 128 by default, see ops.MAP_BWD_MODE).  Otherwise the general route:
+    maps as a tensor, one loss node per image, dense [2n,T,R,R] map gradient."""
+    records = [rec for i, rec in enumerate(controller.step_store["attn"]) if i in args.layers]
+    sides = [int(round(r.q.shape[1] ** 0.5)) for r in records]
+    T = records[0].k.shape[1]
+    n_cand = min(args.furthest_point_num_samples, T)
+    K = min(args.top_k, n_cand)
+    if ops.map_bwd_sparse_supported(sides, K, records[0].R, T) and K >= 2:
+        meta = dict(R=records[0].R, heads=records[0].heads, scales=[r.scale for r in records],
+                    thetas=[thetas[i].reshape(-1).tolist() for i in range(n)], sigma=args.sigma,
+                    num_subjects=getattr(args, "num_subjects", 1), strategy=getattr(args, "top_k_strategy", "gaussian"),
+                    n_cand=n_cand, top_k=K, score_fn=token_order)
+        flat = []
+        for r in records:
+            flat += [r.q, r.k]
+        controller.reset()
+        tot_s, tot_e, _ = ops.MapLossesFn.apply(meta, *flat)
+        return tot_e, tot_s
+    maps = collect_maps_batched(controller, layers=args.layers)  # [2n,T,R,R]
+    dev = maps.device
+    tot_e = torch.zeros((), device=dev)
+    tot_s = torch.zeros((), device=dev)
+    rows = maps.unbind(0)                                        # one backward node: the 2n map gradients are stacked once
+    for i in range(n):
+        sharp, equiv, _ = image_losses(rows[i], rows[n + i], thetas[i].reshape(-1).tolist(), args)
+        tot_e = tot_e + equiv
+        tot_s = tot_s + sharp
+    return tot_e, tot_s
+
+
 def group_step(ldm, images, context, args, controller, transform, denom, noise=None, thetas=None):
     """Forward both views of `images` [n,3,H,W] as one batch, losses per image, backward of
     sum_i (w_e*equiv_i + w_s*sharp_i)/denom into `context.grad`.  Returns detached (total, equiv, sharp)."""
@@ -136,14 +169,7 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
     both = torch.cat([images, warped], dim=0)
     ptp_utils.find_pred_noise(ldm, both, context, noise_level=args.noise_level, device=dev, noise=noise,
                               early_exit=True, controllers={dev: controller})
-    maps = collect_maps_batched(controller, layers=args.layers)  # [2n,T,R,R]
-    tot_e = torch.zeros((), device=dev)
-    tot_s = torch.zeros((), device=dev)
-    rows = maps.unbind(0)                                        # one backward node: the 2n map gradients are stacked once
-    for i in range(n):
-        sharp, equiv, _ = image_losses(rows[i], rows[n + i], thetas[i].reshape(-1).tolist(), args)
-        tot_e = tot_e + equiv
-        tot_s = tot_s + sharp
+    tot_e, tot_s = _group_losses(controller, thetas, args, n)
     loss = (tot_e * args.equivariance_attn_loss_weight + tot_s * args.sharpening_loss_weight) / denom
     loss.backward()
     return loss.detach(), tot_e.detach() / denom, tot_s.detach() / denom

@@ -222,3 +222,98 @@ def test_sd15_full_width_step_vs_oracle():
     gref = c_ref.grad
     print("full-width grad: |g|max", gref.abs().max().item(), "max abs diff", (c_gpu.grad.cpu() - gref).abs().max().item())
     torch.testing.assert_close(c_gpu.grad.cpu(), gref, rtol=5e-3, atol=5e-5 * gref.abs().max().item())
+
+
+def _fp64_map_and_grad(S, sides, H, T, R, sel, G):
+    """fp64 autograd reference of the fused map: natural-log logits z = S / log2(e) -> bicubic -> softmax over tokens ->
+    mean over (layer, head); loss = sum_b sum_k <M[b, sel[b,k]], G[b,k]>.  -> (M, [dL/dz_l])."""
+    import torch.nn.functional as F
+    B = S[0].shape[0]
+    zs, acc = [], 0
+    for S_l, s in zip(S, sides):
+        z = (S_l[..., :T].double() / 1.4426950408889634).requires_grad_(True)           # [B,H,s*s,T]
+        zs.append(z)
+        img = z.reshape(B * H, s, s, T).permute(0, 3, 1, 2)
+        up = F.interpolate(img, size=(R, R), mode="bicubic", align_corners=False)      # [B*H,T,R,R]
+        acc = acc + up.softmax(dim=1).reshape(B, H, T, R, R).sum(dim=1)
+    M = acc / (len(S) * H)
+    loss = sum((M[b, sel[b]] * G[b].double()).sum() for b in range(B))
+    return M.detach(), torch.autograd.grad(loss, zs)
+
+
+@pytest.mark.parametrize("case", [
+    dict(sides=[16, 16, 16, 32], H=8, T=77, R=128, B=2, K=10),            # BASELINE config 2 launch shape (banded)
+    dict(sides=[16, 32], H=8, T=500, R=128, B=1, K=10, bands=1),          # reference-default T, whole image per wave
+    dict(sides=[16, 32], H=8, T=300, R=128, B=1, K=10),                    # T > 128, banded
+    dict(sides=[8, 16], H=8, T=77, R=128, B=1, K=10),                     # 256^2 input (configs[0]): ratios 16 and 8
+    dict(sides=[24], H=5, T=77, R=128, B=1, K=30),                        # SD-2.1 @768^2: non-integer ratio, K = 30, H % 4 != 0
+    dict(sides=[4, 4, 4, 8], H=4, T=12, R=16, B=3, K=5),                  # G2 / tiny-model shapes
+    dict(sides=[4], H=2, T=13, R=10, B=2, K=3),                           # fractional ratio, two heads
+    dict(sides=[8], H=2, T=9, R=6, B=1, K=2),                             # down-sampling
+    dict(sides=[1, 2], H=4, T=16, R=8, B=1, K=4),                         # degenerate sides
+])
+def test_sparse_map_backward_vs_fp64_and_dense(case, monkeypatch):
+    """skp_attn_map_bwd_sparse_f32 (token-major sweep, sparse gradient rows) against fp64 autograd through
+    F.interpolate(bicubic) + softmax, and against the dense-gradient kernels on the same inputs; repeat run bit-identical."""
+    from stablekeypoints_amd import ops
+    if "bands" in case:
+        monkeypatch.setenv("SKP_MAP_BANDS", str(case["bands"]))
+    sides, H, T, R, B, K = (case[k] for k in ("sides", "H", "T", "R", "B", "K"))
+    g = torch.Generator().manual_seed(7)
+    NT = (T + 15) // 16 * 16
+    S = []
+    for s in sides:
+        S_l = torch.zeros(B, H, s * s, NT)
+        S_l[..., :T] = torch.randn(B, H, s * s, T, generator=g) * 3.0
+        S.append(S_l.cuda())
+    sel = torch.stack([torch.randperm(T, generator=g)[:K] for _ in range(B)]).cuda()
+    G = torch.randn(B, K, R, R, generator=g).cuda()
+    M, lse = ops._map_fwd(S, sides, B, H, T, R)
+    Mref, dz = _fp64_map_and_grad(S, sides, H, T, R, sel, G)
+    torch.testing.assert_close(M.double(), Mref, rtol=1e-4, atol=1e-7)
+    dS = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
+    dS2 = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
+    dM = torch.zeros(B, T, R, R, device="cuda")
+    for b in range(B):
+        dM[b, sel[b]] = G[b]
+    dD = [torch.zeros_like(s_) for s_ in S]
+    ops._map_bwd(S, dD, sides, B, H, T, R, dM, lse)
+    for l in range(len(sides)):
+        ref = dz[l]
+        scale = ref.abs().max().item()
+        assert torch.equal(dS[l], dS2[l])                                     # deterministic
+        assert torch.isfinite(dS[l]).all() and (dS[l][..., T:] == 0).all()    # pad columns written as 0
+        err = (dS[l][..., :T].double() - ref).abs().max().item()
+        err_dense = (dD[l][..., :T].double() - ref).abs().max().item()
+        print(f"layer {l} (s={sides[l]}): |dz|max {scale:.3e}  sparse err {err / scale:.2e}  dense err {err_dense / scale:.2e}")
+        assert err < 2e-5 * scale
+        torch.testing.assert_close(dS[l][..., :T], dD[l][..., :T], rtol=1e-4, atol=2e-5 * scale)
+
+
+def test_group_step_sparse_node_equals_dense_route(monkeypatch):
+    """`group_step` through the single map+losses node (sparse map gradient) against the general route (maps tensor, one
+    loss node per image, dense gradient) on the reduced-width model: same losses, same embedding gradient."""
+    from stablekeypoints_amd import ops
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import default_args, group_step
+    from stablekeypoints_amd.optimize_token import load_ldm
+    ldm, controllers, _ = load_ldm("cuda", "tiny", feature_upsample_res=32)
+    dev, controller = next(iter(controllers.items()))
+    g = torch.Generator().manual_seed(11)
+    n, T = 3, 21
+    images = torch.rand(n, 3, 128, 128, generator=g)
+    ctx = torch.randn(1, T, 768, generator=g)
+    noise = torch.randn(2 * n, 4, 16, 16, generator=g).cuda()
+    thetas = torch.cat([R.affine_matrix(11.0, 0.87, (0.13, -0.21)), R.affine_matrix(-9.0, 0.93, (-0.2, 0.1)),
+                        R.affine_matrix(3.0, 0.99, (0.05, 0.2))])
+    args = default_args(num_tokens=T, feature_upsample_res=32, furthest_point_num_samples=9, top_k=5, batch_size=n)
+    out = {}
+    for mode in ("sparse", "dense"):
+        monkeypatch.setattr(ops, "MAP_BWD_MODE", mode)
+        c = ctx.clone().cuda().requires_grad_(True)
+        loss, eq, sh = group_step(ldm, images, c, args, controller, RandomAffineWithInverse(), denom=n, noise=noise,
+                                  thetas=thetas)
+        out[mode] = (loss.item(), eq.item(), sh.item(), c.grad.clone())
+    assert out["sparse"][:3] == pytest.approx(out["dense"][:3], rel=1e-6)
+    gref = out["dense"][3]
+    torch.testing.assert_close(out["sparse"][3], gref, rtol=1e-4, atol=1e-5 * gref.abs().max().item())
