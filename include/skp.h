@@ -97,6 +97,14 @@ int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[h
                          const int* s /*[host]*/, int L, int B, int H, int T, int R,
                          const float* dM, const float* lse, float* workspace, void* stream);
 
+/* One-pass forward for a WIDE token axis (128 < T <= 1024; the reference CLI default is --num_tokens 500, main.py:77-79):
+ * same result as skp_attn_map_fwd_f32, the tokens of a pixel spread over ceil(T/64) lanes (csrc/skp_attn_map_wide.hip)
+ * instead of token groups x two passes.  S[l] rows have stride ldt >= 16*ceil(T/16).  lse: [B,L*H,R*R] written.
+ * tokrow (device, [T] int32, or NULL): output row of token t or -1 -- only those rows of M are written and M is
+ * [B,n_rows,R,R] (optimize.py:58-59 keeps `indices` of the T maps); NULL: M is [B,T,R,R].  Requires R % 32 == 0. */
+int skp_attn_map_fwd_wide_f32(const float* const* S /*[host]*/, const int* s /*[host]*/, int L, int B, int H, int T,
+                              int R, float* M, float* lse, const int* tokrow, int n_rows, int ldt, void* stream);
+
 /* Backward of the fused map for a SPARSE map gradient: the losses of optimize.py:157-206 index the map with the K
  * selected tokens (optimize.py:395-414), so dM is non-zero on K rows per batch row only.
  *   sel: [B,K] int64 token ids (distinct per row), G: [B,K,R,R] = those rows of dM (NOT divided by L*H),

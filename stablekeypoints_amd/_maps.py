@@ -46,9 +46,13 @@ def collect_maps(controller, from_where=["up_cross"], upsample_res=512, layers=[
     if not chosen:
         raise RuntimeError("collect_maps: no stored attention layer matches `layers`")
     if all(isinstance(r, FusedAttn) for r in chosen):
-        m = fused_maps(chosen).mean(dim=0)                        # mean over the batch rows (B*h axis)
-        if indices is not None:
-            m = m[torch.as_tensor(indices, device=m.device)]
+        if indices is not None and not torch.is_grad_enabled():  # inference: only the asked-for rows are computed / written
+            m = ops.attn_map_rows([r.q for r in chosen], [r.k for r in chosen], chosen[0].heads,
+                                  [r.scale for r in chosen], chosen[0].R, indices).mean(dim=0)
+        else:
+            m = fused_maps(chosen).mean(dim=0)                    # mean over the batch rows (B*h axis)
+            if indices is not None:
+                m = m[torch.as_tensor(indices, device=m.device)]
         if upsample_res != -1 and m.shape[0] ** 0.5 != upsample_res:
             # bilinear resize is linear, so it commutes with the layer/head mean
             m = F.interpolate(m[None], size=(upsample_res, upsample_res), mode="bilinear", align_corners=False)[0]
@@ -73,9 +77,14 @@ def collect_maps(controller, from_where=["up_cross"], upsample_res=512, layers=[
     return out
 
 
-def collect_maps_batched(controller, layers=(0, 1, 2, 3)) -> torch.Tensor:
-    """[B,T,R,R]: one reduced map per batch row (the batched engine's variant); resets the controller."""
+def collect_maps_batched(controller, layers=(0, 1, 2, 3), indices=None) -> torch.Tensor:
+    """[B,T,R,R]: one reduced map per batch row (the batched engine's variant); resets the controller.
+    `indices` (inference, no autograd): only those tokens' maps, [B,len(indices),R,R]."""
     chosen = [rec for i, rec in enumerate(controller.step_store["attn"]) if i in layers]
-    out = fused_maps(chosen)
+    if indices is None:
+        out = fused_maps(chosen)
+    else:
+        R, heads = chosen[0].R, chosen[0].heads
+        out = ops.attn_map_rows([r.q for r in chosen], [r.k for r in chosen], heads, [r.scale for r in chosen], R, indices)
     controller.reset()
     return out

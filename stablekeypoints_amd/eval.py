@@ -108,9 +108,9 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     views = tr(image[None].repeat(thetas.shape[0], 1, 1, 1), theta=thetas)
     ptp_utils.find_pred_noise(ldm, views, context.to(dev), noise_level=noise_level, device=dev, noise=noise,
                               early_exit=True, controllers={dev: controller})
-    maps = collect_maps_batched(controller, layers=layers)                  # [n,T,R,R]
     idx = torch.as_tensor(indices, device=dev).long()
-    maps = F.interpolate(maps[:, idx], size=(upscale_size, upscale_size), mode="bilinear", align_corners=False)
+    maps = collect_maps_batched(controller, layers=layers, indices=idx)    # [n,K,R,R]: only the selected tokens' maps
+    maps = F.interpolate(maps, size=(upscale_size, upscale_size), mode="bilinear", align_corners=False)
     num = tr.inverse(torch.ones_like(maps)).sum(dim=0)
     tot = tr.inverse(maps).sum(dim=0)
     return finish_augmented(tot, num, reduce=world > 1)

@@ -63,14 +63,35 @@ def _log2sumexp2(xs: List[torch.Tensor]) -> torch.Tensor:
     return m + torch.log2(torch.exp2(st - m).sum(dim=0))
 
 
-def _map_fwd(S: Sequence[torch.Tensor], sides: Sequence[int], B: int, H: int, T: int, R: int):
-    """-> (M [B,T,R,R], lse [B,L*H,R*R] log2-sum-exp over all tokens).  T > 128 runs token groups in two
-    passes (group statistics -> combine -> apply)."""
+MAP_WIDE = os.environ.get("SKP_MAP_WIDE", "1") != "0"          # A/B switch: "0" = token groups x two passes for T > 128
+MAP_WIDE_MAX_T = 1024
+
+
+def map_wide_supported(T: int, R: int) -> bool:
+    return MAP_WIDE and TOKEN_GROUP < T <= MAP_WIDE_MAX_T and R % 32 == 0
+
+
+def _map_fwd(S: Sequence[torch.Tensor], sides: Sequence[int], B: int, H: int, T: int, R: int, tokrow=None, n_rows: int = 0):
+    """-> (M [B,T,R,R], lse [B,L*H,R*R] log2-sum-exp over all tokens).  T <= 128: all tokens of a pixel in one lane;
+    more tokens: ONE pass with the token axis in 64-token slices across lanes (csrc/skp_attn_map_wide.hip); shapes that
+    kernel does not take run token groups in two passes (group statistics -> combine -> apply).
+    `tokrow` (int32 [T] on the device: output row of a token or -1) restricts the written maps to `n_rows` rows -- wide
+    kernel only."""
     dev = S[0].device
     L, ldt = len(S), S[0].shape[-1]
-    M = torch.empty(B, T, R, R, device=dev, dtype=torch.float32)
     si, _k2 = N.int_array(sides)
     lib, st = N.lib(), _stream()
+    if map_wide_supported(T, R):
+        M = torch.empty(B, n_rows if tokrow is not None else T, R, R, device=dev, dtype=torch.float32)
+        lse = torch.empty(B, L * H, R * R, device=dev, dtype=torch.float32)
+        sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
+        N.check(lib.skp_attn_map_fwd_wide_f32(sp, si, L, B, H, T, R, M.data_ptr(), lse.data_ptr(),
+                                              tokrow.data_ptr() if tokrow is not None else None, int(n_rows), ldt, st),
+                "skp_attn_map_fwd_wide_f32")
+        return M, lse
+    if tokrow is not None:
+        raise RuntimeError("_map_fwd: row selection is served by the wide-token kernel only")
+    M = torch.empty(B, T, R, R, device=dev, dtype=torch.float32)
 
     def launch(t0, t1, mode, lse_out, lse_in):
         sp, _k1 = N.ptr_array([t.data_ptr() + 4 * t0 for t in S])
@@ -228,6 +249,27 @@ def attn_map(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], heads: int,
     for q, k in zip(qs, ks):
         flat += [q, k]
     return AttnMapFn.apply(int(R), int(heads), tuple(float(s) for s in scales), *flat)
+
+
+@torch.no_grad()
+def attn_map_rows(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], heads: int, scales: Sequence[float], R: int,
+                  indices: torch.Tensor) -> torch.Tensor:
+    """[B,len(indices),R,R]: the maps of the tokens `indices` only (optimize.py:58-59 `data[:, :, :, indices]`; inference
+    keeps K of the T maps).  With a wide token axis (T > 128) the kernel writes just those rows -- the softmax still runs
+    over all T tokens; otherwise all T maps are written and gathered.  No autograd (inference path)."""
+    T = ks[0].shape[1]
+    idx = torch.as_tensor(indices, device=qs[0].device).long().reshape(-1)
+    sides = [int(round(q.shape[1] ** 0.5)) for q in qs]
+    S = [qk_logits(q.detach(), k.detach(), heads, sc) for q, k, sc in zip(qs, ks, scales)]
+    B = qs[0].shape[0]
+    if map_wide_supported(T, R):
+        uniq, inv = torch.unique(idx, return_inverse=True)      # a token asked for twice is written once
+        tokrow = torch.full((T,), -1, device=idx.device, dtype=torch.int32)
+        tokrow[uniq] = torch.arange(uniq.numel(), device=idx.device, dtype=torch.int32)
+        M, _ = _map_fwd(S, sides, B, heads, T, R, tokrow=tokrow, n_rows=int(uniq.numel()))
+        return M if uniq.numel() == idx.numel() and bool((inv == torch.arange(idx.numel(), device=idx.device)).all()) else M[:, inv]
+    M, _ = _map_fwd(S, sides, B, heads, T, R)
+    return M[:, idx]
 
 
 def materialize_probs(q: torch.Tensor, k: torch.Tensor, heads: int, scale: float, R: int) -> torch.Tensor:

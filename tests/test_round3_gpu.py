@@ -317,3 +317,40 @@ def test_group_step_sparse_node_equals_dense_route(monkeypatch):
     assert out["sparse"][:3] == pytest.approx(out["dense"][:3], rel=1e-6)
     gref = out["dense"][3]
     torch.testing.assert_close(out["sparse"][3], gref, rtol=1e-4, atol=1e-5 * gref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [
+    dict(sides=[16, 16, 16, 32], H=8, T=500, R=128, B=2),        # reference-default token count at the step's shapes
+    dict(sides=[16, 32], H=8, T=129, R=128, B=1),                # just past the narrow kernel's range
+    dict(sides=[8, 16], H=4, T=300, R=64, B=2),                  # 19 x 16 tokens: a partly filled last slice
+    dict(sides=[24], H=5, T=1000, R=96, B=1),                    # 64-token slices, fractional ratio, odd head count
+    dict(sides=[4, 8], H=2, T=200, R=32, B=3),                   # one 32-pixel tile per row
+])
+def test_wide_token_forward_one_pass_vs_fp64_and_grouped(case, monkeypatch):
+    """skp_attn_map_fwd_wide_f32 (T > 128 in one pass, token slices across lanes) against fp64 autograd-free reference
+    (F.interpolate bicubic + softmax), against the grouped two-pass kernels (maps AND lse), and with a row selection."""
+    from stablekeypoints_amd import ops
+    sides, H, T, R, B = (case[k] for k in ("sides", "H", "T", "R", "B"))
+    g = torch.Generator().manual_seed(9)
+    NT = (T + 15) // 16 * 16
+    S = []
+    for s in sides:
+        S_l = torch.zeros(B, H, s * s, NT)
+        S_l[..., :T] = torch.randn(B, H, s * s, T, generator=g) * 4.0
+        S.append(S_l.cuda())
+    assert ops.map_wide_supported(T, R)
+    M, lse = ops._map_fwd(S, sides, B, H, T, R)
+    sel = torch.zeros(B, 1, dtype=torch.long)
+    Mref, _ = _fp64_map_and_grad(S, sides, H, T, R, sel.cuda(), torch.zeros(B, 1, R, R, device="cuda"))
+    torch.testing.assert_close(M.double(), Mref, rtol=1e-4, atol=1e-8)
+    assert torch.allclose(M.sum(dim=1), torch.ones_like(M[:, 0]), atol=1e-5)
+    monkeypatch.setattr(ops, "MAP_WIDE", False)
+    M2, lse2 = ops._map_fwd(S, sides, B, H, T, R)
+    monkeypatch.setattr(ops, "MAP_WIDE", True)
+    torch.testing.assert_close(M, M2, rtol=2e-5, atol=1e-9)
+    torch.testing.assert_close(lse, lse2, rtol=1e-5, atol=1e-5)
+    idx = torch.randperm(T, generator=g)[:7]
+    tokrow = torch.full((T,), -1, dtype=torch.int32)
+    tokrow[idx] = torch.arange(7, dtype=torch.int32)
+    Msel, lse3 = ops._map_fwd(S, sides, B, H, T, R, tokrow=tokrow.cuda(), n_rows=7)
+    assert Msel.shape == (B, 7, R, R) and torch.equal(Msel, M[:, idx.cuda()]) and torch.equal(lse3, lse)

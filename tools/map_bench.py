@@ -54,6 +54,14 @@ def main():
         dM[b, sel[b]] = G[b]
     print(f"B={B} T={T} R={R} H={H} sides={sides} K={K}")
     timed("map forward", lambda: ops._map_fwd(S, sides, B, H, T, R), a.iters)
+    if T > 128 and ops.map_wide_supported(T, R):
+        ops.MAP_WIDE = False
+        timed("map forward, token groups x two passes", lambda: ops._map_fwd(S, sides, B, H, T, R), a.iters)
+        ops.MAP_WIDE = True
+        tokrow = torch.full((T,), -1, dtype=torch.int32)
+        tokrow[sel[0].cpu()] = torch.arange(K, dtype=torch.int32)
+        tokrow = tokrow.to(dev)
+        timed(f"map forward, {K} rows written", lambda: ops._map_fwd(S, sides, B, H, T, R, tokrow=tokrow, n_rows=K), a.iters)
     if not a.skip_dense:
         dD = [torch.zeros_like(x) for x in S]
         timed("map backward, dense gradient (A + B)", lambda: ops._map_bwd(S, dD, sides, B, H, T, R, dM, lse), a.iters)
