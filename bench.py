@@ -63,13 +63,19 @@ def parse():
                     help="EXPERIMENT (separate line, never the bench of record): frozen nn.Linear GEMMs on the bf16 matrix "
                          "cores with three-term operand splits (csrc/skp_gemm_x3.hip)")
     ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
+                    help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/traffic_probe.py on "
+                         "this box (auto: when rocprofv3 is on PATH and N = 1), file = the committed profiles/r*_pmc_*.json")
+    ap.add_argument("--verify", default="auto", choices=["auto", "on", "off"],
+                    help="host-drawn weights on BOTH legs and one 256^2 image through the oracle's reference-order CPU step and the "
+                         "MI355X step: loss / gradient agreement goes into the line (auto: with the CPU baseline leg)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-fuse-norms", action="store_true", help="A/B: keep ATen GroupNorm/SiLU in the frozen blocks")
     return ap.parse_args()
 
 
-def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None):
+def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None, top_k=10):
     """Time the fused map kernels alone at the bench shapes (default SD-1.5 hooked layers: 3 x (16^2, C=1280) +
     1 x (32^2, C=640), 8 heads) with events on the CURRENT stream (the one the C-ABI launches on)."""
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -83,7 +89,14 @@ def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None):
     S = [ops.qk_logits(q, k, H, sc) for q, k, sc in zip(qs, ks, scales)]
     sides = [s for s, _ in dims]
     M, lse = ops._map_fwd(S, sides, B, H, T, R)
-    dM = torch.randn_like(M)
+    # the gradient the step produces: K selected rows per batch row (optimize.py:395-414), dense form for the dense kernels
+    Kk = min(top_k, T)
+    sel = torch.stack([torch.randperm(T, generator=g)[:Kk] for _ in range(B)]).to(device)
+    G = torch.randn(B, Kk, R, R, generator=g).to(device)
+    sparse = ops.map_bwd_sparse_supported(sides, Kk, R, T)
+    dM = torch.zeros_like(M)
+    for b in range(B):
+        dM[b, sel[b]] = G[b]
     dS = [torch.empty_like(s_) for s_ in S]
     from stablekeypoints_amd import _native as N
     sp, k1 = N.ptr_array([t.data_ptr() for t in S])
@@ -93,11 +106,13 @@ def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None):
     ws = torch.empty(max(4, N.lib().skp_attn_map_bwd_workspace(si, L, B, H, min(T, 128), R)) // 4, device=device)
 
     def run_fwd():
-        if T > 128:                                              # token-group path (several launches)
+        if T > 128:                                              # one-pass wide kernel (or token groups)
             return ops._map_fwd(S, sides, B, H, T, R)
         N.check(N.lib().skp_attn_map_fwd_f32(sp, si, L, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "fwd")
 
     def run_bwd():
+        if sparse:                                               # the route ops.MapLossesFn takes at this T
+            return ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
         if T > 128:
             return ops._map_bwd(S, dS, sides, B, H, T, R, dM, lse)
         N.check(N.lib().skp_attn_map_bwd_f32(sp, dp, si, L, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "bwd")
@@ -120,6 +135,10 @@ def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None):
     fwd_bytes = B * (q_b + m_b) + k_b
     bwd_bytes = B * (m_b + q_b + q_b) + 2 * k_b + k_b
     flops_equiv = B * sum(2 * R * R * C * T for _, C in dims)   # the reference's direct up-res contraction
+    out["fwd_kernel"] = ("skp_attn_map_fwd_wide_kernel (one pass, token slices)" if ops.map_wide_supported(T, R) else
+                         "skp_attn_map_fwd_kernel" + (" (token groups x two passes)" if T > 128 else ""))
+    out["bwd_route"] = ("sparse gradient rows, token-major sweep (skp_map_bwd_tok_kernel)" if sparse else
+                        "dense gradient (skp_attn_map_bwd_kernel + vadj)")
     return out, fwd_bytes, bwd_bytes, flops_equiv
 
 
@@ -216,8 +235,11 @@ def cpu_baseline(ldm_cpu, args):
             "sample": f"{size}x{size}: 1 warm-up + 3 timed optimizer steps (batch 1: 2 VAE+UNet forwards with materialised "
                       f"attention, backward, Adam per step), T={args.tokens}, R={args.res}, {sec:.1f} s; torch "
                       f"{torch.__version__} CPU fp32, {best} threads of {ncpu}",
-            "c1_256": {"value": c1_rate, "steps": c1_steps, "seconds": c1_sec,
-                       "what": "BASELINE config 1 shape (256^2, 1 image, batch 1), reference op order"},
+            "c1_256": {"value": c1_rate, "steps": c1_steps, "seconds": c1_sec, "sampled": c1_steps < 50,
+                       "full_protocol_steps": 50,
+                       "what": "BASELINE config 1 shape (256^2, 1 image, batch 1), reference op order"
+                               + ("" if c1_steps >= 50 else f" -- a {c1_steps}-step SAMPLE of the 50-step protocol "
+                                  "(--cpu-baseline full runs all 50)")},
             "thread_sweep_256_images_per_sec": {str(k): v for k, v in sweep.items()}}
 
 
@@ -237,6 +259,85 @@ def measured_traffic(kernel_substr):
             if kernel_substr in plain and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "profiles/" + os.path.basename(path)
     return None, None
+
+
+def live_traffic(a, rows, image_size):
+    """HBM bytes per launch of the roofline kernels measured NOW: two counter-only rocprofv3 passes (FETCH_SIZE, then
+    WRITE_SIZE -- they do not fit one pass; never combined with a trace) over tools/traffic_probe.py.  FETCH_SIZE is
+    doubled per MI355X_MICROARCH.md (HBM section).  -> {kernel name: bytes} or None."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    probe = [sys.executable, os.path.join(ROOT, "tools", "traffic_probe.py"), "--rows", str(rows), "--tokens", str(a.tokens),
+             "--res", str(a.res), "--image-size", str(min(image_size, 512)), "--top-k", str(a.top_k)]
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="skp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "-f", "csv", "-d", out, "-o", "p", "--"] + probe, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            per = {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+                    if "skp_" not in k:
+                        continue
+                    if "_conv_" in k:
+                        k += "@grid" + row["Grid_Size"]
+                    d = per.setdefault(k, {})
+                    d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            for k, d in per.items():
+                acc.setdefault(k, {})[counter] = sum(d.values()) / len(d)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) for k, c in acc.items()
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+
+
+def verify_against_oracle(ldm_cpu, ldm, controller, a, dev):
+    """One 256^2 image (BASELINE configs[0]'s shape) through the oracle's reference-order CPU step and through the MI355X
+    step, SAME weights (drawn on the host, copied to the GPU), same noise and affine: the line carries the agreement."""
+    from oracle import cpu_path, ref_path as R
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import default_args, group_step
+    g = torch.Generator().manual_seed(5)
+    size = 256 if a.model.startswith("sd") else 128
+    image = torch.rand(1, 3, size, size, generator=g)
+    width = ldm_cpu.unet.config["cross_attention_dim"]
+    ctx = torch.randn(1, a.tokens, width, generator=g) * 5.0
+    noise = torch.randn(2, 4, size // 8, size // 8, generator=g)
+    theta = R.affine_matrix(9.0, 0.9, (0.1, -0.15))
+    args = default_args(num_tokens=a.tokens, feature_upsample_res=a.res, furthest_point_num_samples=a.candidates,
+                        top_k=a.top_k, batch_size=1)
+    store = R.OracleStore()
+    cpu_path.register_reference_hook(ldm_cpu.unet, store, a.res)
+    c_ref = ctx.clone().requires_grad_(True)
+    t0 = time.perf_counter()
+    loss, sharp, equiv, sel, am, am_t = cpu_path.image_step(ldm_cpu, image, c_ref, store, theta, noise[0:1], noise[1:2],
+                                                            furthest_point_num_samples=a.candidates, top_k=a.top_k,
+                                                            sigma=args.sigma)
+    loss.backward()
+    cpu_s = time.perf_counter() - t0
+    c_gpu = ctx.clone().to(dev).requires_grad_(True)
+    lg, eg, sg = group_step(ldm, image, c_gpu, args, controller, RandomAffineWithInverse(), denom=1, noise=noise.to(dev),
+                            thetas=theta)
+    gref, ggpu = c_ref.grad, c_gpu.grad.cpu()
+    return {"what": f"1 image {size}x{size}, T={a.tokens}, R={a.res}: oracle reference-order CPU step vs the MI355X step, same "
+                    "host-drawn weights / noise / affine",
+            "loss_cpu": float(loss), "loss_gpu": float(lg), "loss_rel_diff": abs(float(lg) - float(loss)) / abs(float(loss)),
+            "sharpening_rel_diff": abs(float(sg) - float(sharp)) / abs(float(sharp)),
+            "equivariance_rel_diff": abs(float(eg) - float(equiv)) / abs(float(equiv)),
+            "grad_max_abs_diff_over_max": float((ggpu - gref).abs().max() / gref.abs().max()),
+            "grad_cosine": float(torch.nn.functional.cosine_similarity(ggpu.flatten(), gref.flatten(), dim=0)),
+            "cpu_step_seconds": cpu_s}
 
 
 NATIVE_SIZE = {"sd15": 512, "sd21": 768, "sdxl": 1024, "tiny": 128, "tiny-sd21": 128, "tiny-sdxl": 128}
@@ -298,14 +399,27 @@ def main():
     t_build = time.time()
     cpu_stats = None
     want_cpu = a.cpu_baseline in ("on", "full") or (a.cpu_baseline == "auto" and world == 1 and a.model == "sd15")
-    if want_cpu and rank == 0:
-        # the CPU leg gets its own host-side instance (same seed => the same numbers the GPU tree would draw on the host)
+    want_verify = a.verify == "on" or (a.verify == "auto" and want_cpu)
+    ldm_cpu = None
+    if (want_cpu or want_verify) and rank == 0:
+        # the CPU leg gets its own host-side instance (seeded host draw)
         ldm_cpu, _, _ = load_ldm("cpu", a.model, feature_upsample_res=a.res)
-        cpu_stats = cpu_baseline(ldm_cpu, a)
-        del ldm_cpu
+        if want_cpu:
+            cpu_stats = cpu_baseline(ldm_cpu, a)
     # frozen weights are drawn on this rank's GPU (seeded: identical on every rank; no N x 3.4 GB of host-side init)
     ldm, controllers, _ = load_ldm(dev, a.model, feature_upsample_res=a.res, init_on_device=True)
     controller = controllers[dev]
+    verify = None
+    weights_init = "seeded, drawn on the rank's GPU"
+    if want_verify and rank == 0 and world == 1:
+        with torch.no_grad():                                    # BOTH legs on the host-drawn weights
+            for src, dst in ((ldm_cpu.unet, ldm.unet), (ldm_cpu.vae, ldm.vae)):
+                sd = src.state_dict()
+                for k, v in dst.state_dict().items():
+                    v.copy_(sd[k])
+        weights_init = "seeded, drawn on the host, copied to the GPU (the CPU legs use the same tensors)"
+        verify = verify_against_oracle(ldm_cpu, ldm, controller, a, dev)
+    del ldm_cpu
     if a.miopen_find:
         torch.backends.cudnn.benchmark = True
     if a.channels_last:
@@ -371,14 +485,31 @@ def main():
     if rank == 0:
         B = 2 * per_rank                                          # rows per fused-map launch (both views)
         ldims = hooked_layer_dims(a.model, image_size)
-        kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev, ldims)
+        kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev, ldims, a.top_k)
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(10, a.kernel_iters // 3), dev)
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
         issue1, issue2 = ops.mfma_issue_rate(1, device=dev), ops.mfma_issue_rate(2, device=dev)
         conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}")
-        map_traffic, map_src = measured_traffic("skp_attn_map_fwd_kernel")
+        map_kernel = "skp_attn_map_fwd_wide_kernel" if ops.map_wide_supported(a.tokens, a.res) else "skp_attn_map_fwd_kernel"
+        map_traffic, map_src = measured_traffic(map_kernel)
+        live, map_bwd_traffic = None, None
+        if a.traffic == "live" or (a.traffic == "auto" and world == 1 and a.model == "sd15"):
+            torch.cuda.empty_cache()
+            live = live_traffic(a, B, image_size)
+        if live:
+            src = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/traffic_probe.py in this run (2 x FETCH + WRITE)"
+            for k, v in live.items():
+                if "skp_wino4_conv_c128_kernel" in k:
+                    conv_traffic, conv_src = v, src
+                if map_kernel in k:
+                    map_traffic, map_src = v, src
+            bwd_parts = {k: v for k, v in live.items() if any(t in k for t in ("map_bwd", "map_dot", "map_vadj", "map_taps"))}
+            if bwd_parts:                                        # every kernel of the backward route launches once per backward
+                map_bwd_traffic = {"total": sum(bwd_parts.values()), "by_kernel": bwd_parts}
+        elif a.traffic == "off":
+            conv_traffic = conv_src = map_traffic = map_src = None
         cfg_name = CONFIG_NAME.get(a.model, "reduced-width test model")
         if a.model == "sd15" and a.scaling == "strong":
             cfg_name = "BASELINE config 3 (fixed global batch)"
@@ -409,12 +540,13 @@ def main():
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
                          "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
             # the north-star attention kernel (BASELINE metric: "fraction of the attention roofline")
-            "roofline_attn_map": {"kernel": "skp_attn_map_fwd_kernel (fused up-res softmax map, forward)",
+            "roofline_attn_map": {"kernel": kt["fwd_kernel"] + " (fused up-res softmax map, forward)", "bwd_route": kt["bwd_route"],
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": map_traffic, "traffic_source": map_src,
                          "launch_us": kt["fwd"] * 1e6, "algorithmic_bytes": fwd_bytes, "rows_per_launch": B,
                          "bwd_launch_us": kt["bwd"] * 1e6, "bwd_achieved": bwd_bytes / kt["bwd"] / 1e9,
                          "bwd_frac": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS, "bwd_algorithmic_bytes": bwd_bytes,
+                         "bwd_traffic": map_bwd_traffic,
                          "reference_contraction_equiv_tflops": flops_equiv / kt["fwd"] / 1e12,
                          "f32_matrix_peak_tflops": F32_MATRIX_PEAK_TF},
             "roofline_self_attn": {"kernel": "flash self-attention forward, 64^2 layers (N=4096, 8 heads x 40)",
@@ -433,9 +565,10 @@ def main():
             "attention_roofline_frac": {"map_fwd_hbm": ach / HBM_PEAK_GBS, "map_bwd_hbm": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS,
                                         "self_attn_fwd_mfma": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
                                         "self_attn_bwd_mfma": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF},
-            "cpu_baseline": cpu_stats, "collective_check": coll,
+            "traffic_live_kernels": sorted(live) if live else None,
+            "cpu_baseline": cpu_stats, "verify": verify, "collective_check": coll,
             "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
-            "weights_init": "seeded, drawn on the rank's GPU",
+            "weights_init": weights_init,
         }
         if line["roofline"]["traffic"]:
             line["roofline"]["hbm_gbs_at_traffic"] = line["roofline"]["traffic"] / cv_t / 1e9
