@@ -118,6 +118,15 @@ int skp_attn_map_bwd_sparse_f32(const float* const* S /*[host]*/, float* const* 
                                 int L, int B, int H, int T, int R, const int64_t* sel, const float* G, int K,
                                 const float* lse, void* workspace, int ldt, void* stream);
 
+/* Tail of the augmented inference (eval.py:239-353) for n views of one image and K selected tokens, one kernel:
+ *   tot[k] = sum_v grid_sample(bilinear_{R->S}(M[v,k]), affine_grid(theta_inv[v]))     (bilinear, zeros, align_corners=False)
+ *   num    = sum_v grid_sample(ones,                    affine_grid(theta_inv[v]))     (coverage; the same for every k)
+ * M: [n,K,R,R]; theta_inv: [n,6] (device) = the INVERSE 2x3 affine of every view (invertable_transform.py:77-84);
+ * tot: [K,S,S] written; num: [S,S] written (may be NULL).  finish != 0: tot = tot / num with 0/0 -> 0 (eval.py:343-346).
+ * Limits: K <= 32. */
+int skp_unwarp_accumulate_f32(const float* M, const float* theta_inv, int n, int K, int R, int S, float* tot, float* num,
+                              int finish, void* stream);
+
 /* Ordinary cross-attention core (ptp_utils.py:493-506,540) for a short key axis, fp32 MFMA, K/V staged in
  * LDS, softmax over the tokens in registers:
  *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]

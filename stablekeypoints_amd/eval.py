@@ -78,8 +78,6 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     from . import ptp_utils
     from ._maps import collect_maps_batched
     from .invertable_transform import RandomAffineWithInverse
-    import torch.nn.functional as F
-
     if visualize:
         raise NotImplementedError("plotting is out of scope (SURVEY.md 2.1 row 14)")
     dev, controller = next(iter(controllers.items()))
@@ -110,10 +108,13 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
                               early_exit=True, controllers={dev: controller})
     idx = torch.as_tensor(indices, device=dev).long()
     maps = collect_maps_batched(controller, layers=layers, indices=idx)    # [n,K,R,R]: only the selected tokens' maps
-    maps = F.interpolate(maps, size=(upscale_size, upscale_size), mode="bilinear", align_corners=False)
-    num = tr.inverse(torch.ones_like(maps)).sum(dim=0)
-    tot = tr.inverse(maps).sum(dim=0)
-    return finish_augmented(tot, num, reduce=world > 1)
+    # resize R -> upscale_size, un-warp the maps and a ones mask, sum over the views: ONE kernel (the reference's four
+    # [n,K,S,S] intermediates are never materialised); a single rank gets sum / count straight from it
+    theta_inv = RandomAffineWithInverse.invert(thetas.to(torch.float32))
+    tot, num = ops.unwarp_accumulate(maps, theta_inv, int(upscale_size), finish=(world == 1))
+    if world == 1:
+        return tot
+    return finish_augmented(tot, num[None].expand_as(tot).contiguous(), reduce=True)
 
 
 def finish_augmented(tot, num, reduce=True):

@@ -439,6 +439,27 @@ class MapLossesFn(torch.autograd.Function):
         return (None, *_dqk_from_dS(qs, ks, dS, scales, H, T, ctx.needs_input_grad[1:]))
 
 
+UNWARP_MAX_K = 32
+
+
+@torch.no_grad()
+def unwarp_accumulate(maps: torch.Tensor, theta_inv: torch.Tensor, size: int, finish: bool = True):
+    """Tail of the augmented inference (eval.py:239-353): maps [n,K,R,R] of n views, theta_inv [n,2,3] their inverse
+    affines -> (sum_v unwarp(bilinear_{R->size}(maps[v])) [K,size,size], coverage count [size,size]); with `finish` the
+    first is already sum / count with 0/0 -> 0.  One kernel (csrc/skp_unwarp.hip); K > 32 runs in chunks of 32 tokens."""
+    maps = _dev(maps, "maps")
+    n, K, R, _ = maps.shape
+    th = theta_inv.to(device=maps.device, dtype=torch.float32).reshape(n, 6).contiguous()
+    tot = torch.empty(K, size, size, device=maps.device, dtype=torch.float32)
+    num = torch.empty(size, size, device=maps.device, dtype=torch.float32)
+    for k0 in range(0, K, UNWARP_MAX_K):
+        k1 = min(K, k0 + UNWARP_MAX_K)
+        chunk = maps if (k0 == 0 and k1 == K) else maps[:, k0:k1].contiguous()
+        N.check(N.lib().skp_unwarp_accumulate_f32(chunk.data_ptr(), th.data_ptr(), n, k1 - k0, R, size, tot[k0:k1].data_ptr(),
+                                                  num.data_ptr(), 1 if finish else 0, _stream()), "skp_unwarp_accumulate_f32")
+    return tot, num
+
+
 # ---------------------------------------------------------------------------------------------
 # ordinary cross-attention core (short key axis)                 ptp_utils.py:493-506,540
 # ---------------------------------------------------------------------------------------------

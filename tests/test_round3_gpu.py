@@ -354,3 +354,36 @@ def test_wide_token_forward_one_pass_vs_fp64_and_grouped(case, monkeypatch):
     tokrow[idx] = torch.arange(7, dtype=torch.int32)
     Msel, lse3 = ops._map_fwd(S, sides, B, H, T, R, tokrow=tokrow.cuda(), n_rows=7)
     assert Msel.shape == (B, 7, R, R) and torch.equal(Msel, M[:, idx.cuda()]) and torch.equal(lse3, lse)
+
+
+@pytest.mark.parametrize("n,K,Rm,S", [(5, 10, 128, 512), (3, 4, 32, 64), (2, 33, 16, 40), (4, 7, 24, 100)])
+def test_fused_unwarp_accumulate_vs_torch_ops(n, K, Rm, S):
+    """skp_unwarp_accumulate_f32 (resize R -> S, inverse affine un-warp of maps and coverage, sum over views, sum / count)
+    against the reference's op sequence in torch (eval.py:258-346: F.interpolate bilinear, affine_grid + grid_sample of the
+    maps and of a ones tensor, sums, division, NaN -> 0) on the same GPU."""
+    import torch.nn.functional as F
+    from stablekeypoints_amd import ops
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    g = torch.Generator().manual_seed(3)
+    maps = torch.rand(n, K, Rm, Rm, generator=g).cuda()
+    tr = RandomAffineWithInverse(degrees=30, scale=(0.7, 1.1), translate=(0.3, 0.3))
+    torch.manual_seed(5)
+    thetas = tr.sample_theta(n)
+    tr.last_params = {"theta": thetas}
+    up = F.interpolate(maps, size=(S, S), mode="bilinear", align_corners=False)
+    num_ref = tr.inverse(torch.ones_like(up)).sum(dim=0)
+    tot_ref = tr.inverse(up).sum(dim=0)
+    ref = tot_ref / num_ref
+    ref[ref != ref] = 0
+    theta_inv = RandomAffineWithInverse.invert(thetas)
+    tot, num = ops.unwarp_accumulate(maps, theta_inv, S, finish=False)
+    # sample coordinates are O(S) pixels in fp32: a border pixel's bilinear weight moves by ~S * 2^-23 per view when the
+    # affine is evaluated in another order (fma here, bmm in affine_grid)
+    tol = dict(rtol=1e-5, atol=1e-6 * S * n)
+    torch.testing.assert_close(num, num_ref[0], **tol)
+    torch.testing.assert_close(tot, tot_ref, **tol)
+    out, _ = ops.unwarp_accumulate(maps, theta_inv, S, finish=True)
+    assert (num_ref[0] == 0).any() or n < 3                     # the affines leave uncovered corners: 0/0 -> 0 is exercised
+    assert torch.equal(out[:, num_ref[0] == 0], torch.zeros_like(out[:, num_ref[0] == 0]))
+    covered = num_ref[0] > 0.25                                 # a ratio over a sliver of coverage amplifies the above
+    torch.testing.assert_close(out[:, covered], ref[:, covered], rtol=5e-4, atol=1e-5)     # north_star bar: 1e-3
