@@ -127,6 +127,19 @@ int skp_attn_map_bwd_sparse_f32(const float* const* S /*[host]*/, float* const* 
 int skp_unwarp_accumulate_f32(const float* M, const float* theta_inv, int n, int K, int R, int S, float* tot, float* num,
                               int finish, void* stream);
 
+/* GroupNorm folded into the consuming convolution (forward only; the VAE encoder of ptp_utils.py:289-304 runs without
+ * autograd): skp_group_norm_coef_f32 leaves (scale, shift) per (sample, channel) -- statistics from the producing
+ * convolution's block sums (bs != NULL) or from one pass over x -- and skp_conv3x3_f4_gn_f32 computes
+ * conv3x3(silu(x * scale + shift)) with the normalisation applied in its patch load: the GroupNorm apply pass (one read
+ * and one write of the activation) disappears.  skp_conv3x3_f4_gn_ok: 1 where the convolution runs with a single
+ * output-channel group (Cout <= 128, 128-channel workgroup form, unsplit). */
+int skp_group_norm_coef_f32(const float* x, const float* off, const float* gamma, const float* beta, float* mean, float* rstd,
+                            float* coef, const float* bs, int nblk, int pix, float* workspace, int N, int C, int G, int HW,
+                            float eps, void* stream);
+int skp_conv3x3_f4_gn_ok(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4_gn_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, float* stats,
+                          const float* coef, int B, int Cin, int Cout, int H, int W, void* stream);
+
 /* Ordinary cross-attention core (ptp_utils.py:493-506,540) for a short key axis, fp32 MFMA, K/V staged in
  * LDS, softmax over the tokens in registers:
  *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]

@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -30,6 +30,9 @@ SIGNATURES = {
                                 _i, _i64, _i, _vp],
     "skp_attn_map_bwd_workspace": [C.POINTER(_i), _i, _i, _i, _i, _i],
     "skp_attn_map_bwd_f32": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "skp_group_norm_coef_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _f, _vp],
+    "skp_conv3x3_f4_gn_ok": [_i, _i, _i, _i, _i],
+    "skp_conv3x3_f4_gn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_unwarp_accumulate_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "skp_attn_map_fwd_wide_f32": [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "skp_attn_map_bwd_sparse_workspace": [C.POINTER(_i), _i, _i, _i, _i, _i, _i],

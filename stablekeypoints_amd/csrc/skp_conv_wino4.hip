@@ -81,6 +81,7 @@ struct Wino4Args {
     size_t y_split_stride;
     float* stats;               // optional [B][Cout][tilesPerImg/16][2] = {sum y, sum y^2} per 16-tile block (next GroupNorm), or null
     int sblk;                   // 16-tile blocks per image
+    const float* gncoef;        // GNF kernels: [B][Cin][2] = (scale, shift) of the GroupNorm(+offset) in front of this convolution
 };
 
 // Block statistics without register pressure: every lane parks the sum / sum of squares of its 4x4 outputs in the (idle)
@@ -373,7 +374,10 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
 // two), at the price of two filter operand loads per position instead of one.  LDS stage: [36][4][16] f32x4 = 36 KB.
 constexpr int W4C_STAGE_F4 = 36 * 4 * 16;
 constexpr int W4C_RING = 6;                      // ring slots per channel block (divides 36)
-template <bool STATS>
+// GNF: the input is x, not silu(GroupNorm(x)): every patch value goes through v = x * scale[b,c] + shift[b,c], v / (1 + e^-v)
+// on its way into the input transform (one pass over the activation saved per norm: the GroupNorm apply kernel disappears).
+// Zero padding stays zero: out-of-image rows / columns use (scale, shift) = (0, 0) and silu(0) = 0.
+template <bool STATS, bool GNF = false>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -407,7 +411,31 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     }
     const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
     const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
+    // GNF: per-(image, channel) coefficients of the stage's channel `tc`, fetched with the patch rows
+    const i32x4 crs = skp_make_rsrc(a.gncoef, GNF ? (unsigned)a.B * a.Cin * 8u : 0u);
+    int coff = SKP_OOB;
+    unsigned rowmask = 0;
+    if (GNF) {
+        const int tg = tile0 + tl;
+        const int bq = (tg < a.nTiles ? tg : 0) / a.tilesPerImg;
+        coff = (bq * a.Cin + tc) * 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rowmask |= (roff[i] != SKP_OOB ? 1u : 0u) << i;
+    }
+    f32x2 gcoef = {0.f, 0.f};
     f32x2 d[6][3];                                   // [row][column pair]: (c0,c5), (c1,c2), (c3,c4)
+    auto gn_fetch = [&](int cin0) { if (GNF) gcoef = skp_buf_load_f32x2(crs, coff, cin0 * 8, 0); };
+    auto gn_row = [&](int i) {                       // normalise + SiLU row i of the freshly loaded patch
+        if (GNF) {
+            const bool rv = (rowmask >> i) & 1u;
+            const float sc = rv ? gcoef[0] : 0.f, sh = rv ? gcoef[1] : 0.f;
+            auto act = [](float x, float s, float h) { const float v = fmaf(x, s, h); return v / (1.0f + __expf(-v)); };
+            d[i][0][0] = act(d[i][0][0], lok ? sc : 0.f, lok ? sh : 0.f);
+            d[i][0][1] = act(d[i][0][1], rok ? sc : 0.f, rok ? sh : 0.f);
+            d[i][1][0] = act(d[i][1][0], sc, sh); d[i][1][1] = act(d[i][1][1], sc, sh);
+            d[i][2][0] = act(d[i][2][0], sc, sh); d[i][2][1] = act(d[i][2][1], sc, sh);
+        }
+    };
     auto load_row = [&](int cin0, int i) {
         const int so = cin0 * HW * 4;
         const f32x4 mid = skp_buf_load_f32x4(xrs, roff[i], so, 0);
@@ -457,8 +485,11 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         o_base = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
     }
 
+    gn_fetch(cin_begin);
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_row(cin_begin, i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gn_row(i);
 #pragma unroll
     for (int k = 0; k < 3; ++k) col_pass(k);
 #pragma unroll
@@ -489,7 +520,9 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
                 }
             }
             if (MODE == 0) {
+                if (p == 0) gn_fetch(cin_begin + (s + 1) * 16);
                 if (p < 6) load_row(cin_begin + (s + 1) * 16, p);
+                else if (GNF && p >= 21 && p < 27) gn_row(p - 21);
                 else if (p >= 27 && p < 30) col_pass(p - 27);
                 else if (p >= 30) row_pass_store((s + 1) & 1, p - 30);
             }
@@ -647,7 +680,27 @@ extern "C" int skp_conv3x3_f4_stats_blocks(int B, int Cin, int Cout, int H, int 
 }
 
 static int wino4_run(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace, float* stats,
-                     int B, int Cin, int Cout, int H, int W, void* stream);
+                     int B, int Cin, int Cout, int H, int W, void* stream, const float* gncoef = nullptr);
+
+// 1 when skp_conv3x3_f4_gn_f32 serves this launch: 128-channel workgroup form, ONE channel group (the normalisation is
+// applied once per input value), unsplit.  More output-channel groups would redo the SiLU per group: there the separate
+// GroupNorm apply pass is cheaper (profiles/r03_conv_gn_fold.md).
+extern "C" int skp_conv3x3_f4_gn_ok(int B, int Cin, int Cout, int H, int W) {
+    if (wino4_plan(B, Cin, Cout, H, W) != 1) return 0;
+    const int tiles = B * (H / 4) * (W / 4);
+    return (wino4_use_c128(Cout, tiles) && Cout <= 128) ? 1 : 0;
+}
+
+// y = conv3x3(silu(x * scale[b,c] + shift[b,c])) (+ bias) (+ residual): the GroupNorm(+offset)+SiLU in front of the
+// convolution applied inside the patch load (coef: [B,Cin,2] from skp_group_norm_coef_*); optional output block sums as
+// skp_conv3x3_f4_stats_f32.  Forward only (the VAE encoder runs without autograd).
+extern "C" int skp_conv3x3_f4_gn_f32(const void* x, const void* U, const void* bias, const void* residual, void* y,
+                                     float* stats, const float* coef, int B, int Cin, int Cout, int H, int W, void* stream) {
+    if (!coef) return SKP_E_BADARG;
+    if (!skp_conv3x3_f4_gn_ok(B, Cin, Cout, H, W)) return SKP_E_RANGE;
+    if (stats && skp_conv3x3_f4_stats_blocks(B, Cin, Cout, H, W) == 0) return SKP_E_RANGE;
+    return wino4_run(x, U, bias, residual, y, nullptr, stats, B, Cin, Cout, H, W, stream, coef);
+}
 
 extern "C" int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y,
                                   void* workspace, int B, int Cin, int Cout, int H, int W, void* stream) {
@@ -661,7 +714,7 @@ extern "C" int skp_conv3x3_f4_stats_f32(const void* x, const void* U, const void
 }
 
 static int wino4_run(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace, float* stats,
-                     int B, int Cin, int Cout, int H, int W, void* stream) {
+                     int B, int Cin, int Cout, int H, int W, void* stream, const float* gncoef) {
     if (!x || !U || !y) return SKP_E_BADARG;
     int S = wino4_plan(B, Cin, Cout, H, W);
     if (S == 0) return (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) ? SKP_E_BADARG : SKP_E_RANGE;
@@ -685,6 +738,7 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     a.res = S > 1 ? nullptr : (const float*)residual;
     a.stats = S > 1 ? nullptr : stats;
     a.sblk = a.tilesPerImg / 16;
+    a.gncoef = gncoef;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4), lds_c = (size_t)2 * W4C_STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
@@ -697,6 +751,10 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const bool c128 = wino4_use_c128(Cout, a.nTiles);
@@ -705,8 +763,13 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
         a.ncg = (Cout + 127) / 128;
         a.tb_per_xcd = a.ntb >= 64 ? (a.ntb + 7) / 8 : 0;
         dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
-        if (a.stats) hipLaunchKernelGGL(skp_wino4_conv_c128_kernel<true>, grid, dim3(256), lds_c, st, a);
-        else hipLaunchKernelGGL(skp_wino4_conv_c128_kernel<false>, grid, dim3(256), lds_c, st, a);
+        if (gncoef) {
+            if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<true, true>), grid, dim3(256), lds_c, st, a);
+            else hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<false, true>), grid, dim3(256), lds_c, st, a);
+        } else if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<true>), grid, dim3(256), lds_c, st, a);
+        else hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<false>), grid, dim3(256), lds_c, st, a);
+    } else if (gncoef) {
+        return SKP_E_RANGE;
     } else {                                        // 64 channels x 32 tiles per workgroup
         a.ntb = (a.nTiles + 31) / 32;
         a.ncg = (Cout + 63) / 64;

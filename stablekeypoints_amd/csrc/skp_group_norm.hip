@@ -272,6 +272,50 @@ extern "C" int skp_group_norm_fwd_blocks_f32(const float* x, const float* off, c
     return skp_launch_status();
 }
 
+// (scale, shift) per (sample, channel) of y = (x + off - mean) * rstd * gamma + beta = x * scale + shift, for consumers that
+// apply the normalisation themselves (skp_conv3x3_f4_gn_f32).  partial == nullptr: mean / rstd are read, else finalised here.
+__global__ __launch_bounds__(256) void skp_gn_coef_kernel(GNArgs a, const float* __restrict__ partial, float* __restrict__ mean_io,
+                                                          float* __restrict__ rstd_io, float* __restrict__ coef) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N * a.C) return;
+    const int n = i / a.C, c = i - n * a.C, Cg = a.C / a.G, row = n * a.G + c / Cg;
+    float mean, rstd;
+    if (partial) {
+        skp_gn_finalize(partial, row, a.nsplit, a.L, a.eps, mean, rstd);
+        if (c % Cg == 0) { mean_io[row] = mean; rstd_io[row] = rstd; }
+    } else {
+        mean = mean_io[row]; rstd = rstd_io[row];
+    }
+    const float sc = rstd * a.gamma[c];
+    coef[2 * i] = sc;
+    coef[2 * i + 1] = a.beta[c] + ((a.off ? a.off[i] : 0.f) - mean) * sc;
+}
+
+/* Statistics of GroupNorm(x + off) and the per-(sample, channel) (scale, shift) pairs, without the apply pass.
+ * bs != NULL: statistics from a producing convolution's block sums (as skp_group_norm_fwd_blocks_f32), x is not read;
+ * else a statistics pass over x (workspace: N*G*64*3 floats).  coef: [N,C,2] written; mean, rstd: [N,G] written. */
+extern "C" int skp_group_norm_coef_f32(const float* x, const float* off, const float* gamma, const float* beta, float* mean,
+                                       float* rstd, float* coef, const float* bs, int nblk, int pix, float* workspace, int N,
+                                       int C, int G, int HW, float eps, void* stream) {
+    GNArgs a;
+    int rc = gn_fill(a, x ? x : gamma, off, gamma, beta, N, C, G, HW, eps, 0);
+    if (rc) return rc;
+    if (!mean || !rstd || !coef) return SKP_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nb = (unsigned)((N * C + 255) / 256);
+    if (bs) {
+        if (nblk <= 0 || pix <= 0) return SKP_E_BADARG;
+        if ((long)nblk * pix != HW) return SKP_E_RANGE;
+        hipLaunchKernelGGL(skp_gn_from_blocks_kernel, dim3(N * G), dim3(256), 0, st, a, bs, nblk, pix, mean, rstd);
+        hipLaunchKernelGGL(skp_gn_coef_kernel, dim3(nb), dim3(256), 0, st, a, (const float*)nullptr, mean, rstd, coef);
+    } else {
+        if (!x || !workspace) return SKP_E_BADARG;
+        hipLaunchKernelGGL(skp_gn_stats_kernel, dim3(a.nsplit, N * G), dim3(256), 0, st, a, workspace);
+        hipLaunchKernelGGL(skp_gn_coef_kernel, dim3(nb), dim3(256), 0, st, a, (const float*)workspace, mean, rstd, coef);
+    }
+    return skp_launch_status();
+}
+
 extern "C" int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma, const float* beta,
                                       const float* dy, const float* mean, const float* rstd, float* dx,
                                       float* workspace, int N, int C, int G, int HW, float eps, int silu,

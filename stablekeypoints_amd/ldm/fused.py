@@ -23,18 +23,26 @@ def _resnet_forward(m: ResnetBlock2D):
     def forward(x, temb=None):
         if not ops.group_norm_supported(x, m.norm1.num_groups):
             return orig(x, temb)
-        h = ops.group_norm_silu(x, m.norm1)                              # (statistics from x's producer when it left them)
-        h = ops.conv3x3_auto(h, m.conv1.weight, want_stats=True)         # bias folded into norm2's offset
+        # where the convolution runs with one output-channel group and no autograd (the VAE's first level: 128 -> 128 at the
+        # image resolution, 1 GB activations) the norm is applied inside the convolution's patch load: no apply pass
+        if ops.conv3x3_gn_fold_ok(x, m.norm1, m.conv1.weight):
+            h = ops.conv3x3_gn_silu(x, m.norm1, m.conv1.weight, want_stats=True)
+        else:
+            h = ops.group_norm_silu(x, m.norm1)                          # (statistics from x's producer when it left them)
+            h = ops.conv3x3_auto(h, m.conv1.weight, want_stats=True)     # bias folded into norm2's offset
         off = m.conv1.bias[None, :].expand(x.shape[0], -1)
         if m.time_emb_proj is not None and temb is not None:
             off = off + m.time_emb_proj(F.silu(temb))
-        h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
         bias = m.conv2.bias
+        res = x
         if m.conv_shortcut is not None:
             # 1x1 shortcut = one batched GEMM on the NCHW planes (no layout transposes); its bias joins conv2's
-            x, bias = ops.conv1x1_nobias(x, m.conv_shortcut.weight), _summed_bias(m)
+            res, bias = ops.conv1x1_nobias(x, m.conv_shortcut.weight), _summed_bias(m)
+        if ops.conv3x3_gn_fold_ok(h, m.norm2, m.conv2.weight):
+            return ops.conv3x3_gn_silu(h, m.norm2, m.conv2.weight, off=off.contiguous(), bias=bias, residual=res, want_stats=True)
+        h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
         # bias + shortcut in the conv epilogue; its block sums serve the next block's first norm
-        return ops.conv3x3_auto(h, m.conv2.weight, bias, residual=x, want_stats=True)
+        return ops.conv3x3_auto(h, m.conv2.weight, bias, residual=res, want_stats=True)
     return forward
 
 

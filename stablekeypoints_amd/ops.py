@@ -844,6 +844,60 @@ def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
     return (y + bias[None, :, None, None] if bias is not None else y) + residual
 
 
+# GroupNorm(+offset)+SiLU folded into the consuming Winograd convolution (forward only, single output-channel group):
+# saves the norm's apply pass (one read + one write of the activation); SKP_GN_FOLD=0 for A/B runs.
+GN_FOLD = os.environ.get("SKP_GN_FOLD", "1") != "0"
+
+
+def conv3x3_gn_fold_ok(x, norm: torch.nn.GroupNorm, weight) -> bool:
+    if not (GN_FOLD and x.is_cuda and x.dtype == torch.float32) or (torch.is_grad_enabled() and x.requires_grad):
+        return False
+    if weight.requires_grad or not conv3x3_f4_ok(x.shape, weight.shape) or not group_norm_supported(x, norm.num_groups):
+        return False
+    B, ci, H, W = x.shape
+    return bool(N.lib().skp_conv3x3_f4_gn_ok(B, ci, int(weight.shape[0]), H, W))
+
+
+@torch.no_grad()
+def conv3x3_gn_silu(x, norm: torch.nn.GroupNorm, weight, off=None, bias=None, residual=None, want_stats=False):
+    """conv3x3(silu(GroupNorm(x + off))) (+ bias) (+ residual) with the normalisation applied in the convolution's patch load
+    (csrc/skp_conv_wino4.hip, GNF kernels).  Statistics come from x's producer when it left block sums behind."""
+    x = _dev(x, "x")
+    B, C, H, W = x.shape
+    G, cout = norm.num_groups, int(weight.shape[0])
+    off_c = _dev(off.reshape(B, C), "off") if off is not None else None
+    mean = torch.empty(B, G, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    coef = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
+    blocks = getattr(x, "_skp_blocks", None) if GN_FUSED_STATS else None
+    if blocks is not None and (blocks[0].shape[0] != B or blocks[0].shape[1] != C or blocks[1] * blocks[2] != H * W):
+        blocks = None
+    lib, st = N.lib(), _stream()
+    if blocks is not None:
+        bs, nblk, pix = blocks
+        N.check(lib.skp_group_norm_coef_f32(None, off_c.data_ptr() if off_c is not None else None, norm.weight.data_ptr(),
+                                            norm.bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(),
+                                            bs.data_ptr(), int(nblk), int(pix), None, B, C, G, H * W, float(norm.eps), st),
+                "skp_group_norm_coef_f32")
+    else:
+        ws = torch.empty(B * G * 64 * 3, device=x.device, dtype=torch.float32)
+        N.check(lib.skp_group_norm_coef_f32(x.data_ptr(), off_c.data_ptr() if off_c is not None else None,
+                                            norm.weight.data_ptr(), norm.bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            coef.data_ptr(), None, 0, 0, ws.data_ptr(), B, C, G, H * W, float(norm.eps), st),
+                "skp_group_norm_coef_f32")
+    U = _wino4_filters(weight, False)
+    y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    nblk = conv3x3_stats_blocks(x.shape, weight.shape) if want_stats else 0
+    stats = torch.empty(B, cout, nblk, 2, device=x.device, dtype=torch.float32) if nblk else None
+    N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                      stats.data_ptr() if stats is not None else None, coef.data_ptr(), B, C, cout, H, W, st),
+            "skp_conv3x3_f4_gn_f32")
+    if stats is not None:
+        y._skp_blocks = (stats, nblk, 256)
+    return y
+
+
 def conv3x3_small(x, weight, bias=None):
     """3x3 / stride 1 / padding 1 convolution with <= 4 input channels (the conv_in layers), forward only."""
     x, w = _dev(x.detach(), "x"), _dev(weight.detach(), "weight")

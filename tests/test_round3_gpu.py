@@ -387,3 +387,50 @@ def test_fused_unwarp_accumulate_vs_torch_ops(n, K, Rm, S):
     assert torch.equal(out[:, num_ref[0] == 0], torch.zeros_like(out[:, num_ref[0] == 0]))
     covered = num_ref[0] > 0.25                                 # a ratio over a sliver of coverage amplifies the above
     torch.testing.assert_close(out[:, covered], ref[:, covered], rtol=5e-4, atol=1e-5)     # north_star bar: 1e-3
+
+
+@pytest.mark.parametrize("B,C,H,W,use_off,use_res", [(2, 128, 64, 64, False, False), (3, 128, 32, 48, True, True),
+                                                     (1, 64, 128, 128, True, False)])
+def test_group_norm_folded_into_winograd_conv_vs_fp64(B, C, H, W, use_off, use_res, monkeypatch):
+    """conv3x3(silu(GroupNorm(x + off))) + bias + residual with the norm applied inside the convolution's patch load
+    (skp_conv3x3_f4_gn_f32) against fp64 torch ops and against the unfolded route (GroupNorm kernel, then convolution);
+    statistics once from a pass over x, once from a producing convolution's block sums."""
+    import torch.nn.functional as F
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(13)
+    cout = 128
+    x = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3).cuda()
+    norm = torch.nn.GroupNorm(32, C).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    w = (torch.randn(cout, C, 3, 3, generator=g) / (3 * C ** 0.5)).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    off = torch.randn(B, C, generator=g).cuda() if use_off else None
+    res = torch.randn(B, cout, H, W, generator=g).cuda() if use_res else None
+    with torch.no_grad():
+        if not ops.conv3x3_gn_fold_ok(x, norm, w):
+            pytest.skip("shape not served by the folded kernel on this build")
+        y = ops.conv3x3_gn_silu(x, norm, w, off=off, bias=bias, residual=res, want_stats=True)
+        xd = x.double() + (off.double()[:, :, None, None] if use_off else 0)
+        ref = F.conv2d(F.silu(F.group_norm(xd, 32, norm.weight.double(), norm.bias.double(), norm.eps)), w.double(),
+                       bias.double(), padding=1)
+        if use_res:
+            ref = ref + res.double()
+        scale = ref.abs().max().item()
+        print("folded GN + conv: max err / max", ((y.double() - ref).abs().max() / scale).item())
+        assert (y.double() - ref).abs().max().item() < 5e-5 * scale
+        h = ops.group_norm_silu(x, norm, off=off)
+        y2 = ops.conv3x3_auto(h, w, bias, residual=res)
+        torch.testing.assert_close(y, y2, rtol=1e-4, atol=2e-5 * scale)
+        # block sums left behind serve the next norm
+        st, nblk, pix = y._skp_blocks
+        torch.testing.assert_close(st[..., 0].sum(-1), y.sum(dim=(2, 3)), rtol=1e-4, atol=1e-2)
+        # statistics from a producer's block sums
+        x2 = ops.conv3x3_auto(x, (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).cuda(), want_stats=True)
+        if getattr(x2, "_skp_blocks", None) is not None:
+            ya = ops.conv3x3_gn_silu(x2, norm, w, off=off, bias=bias)
+            blk = x2._skp_blocks
+            del x2._skp_blocks
+            yb = ops.conv3x3_gn_silu(x2, norm, w, off=off, bias=bias)
+            torch.testing.assert_close(ya, yb, rtol=1e-4, atol=2e-5 * yb.abs().max().item())

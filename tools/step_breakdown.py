@@ -27,11 +27,12 @@ def main():
     rows = []
     with open(path) as f:
         for row in csv.DictReader(f):
-            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
+            rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"],
+                         row.get("Grid_Size") or "x".join(row.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))))
     rows.sort()
     # one optimizer step = one burst of multi_tensor_apply kernels; boundary = end of the last kernel of a burst
     bounds, last = [], None
-    for st, en, name in rows:
+    for st, en, name, _ in rows:
         if "multi_tensor_apply" in name:
             if last is not None and st - last < 2_000_000:
                 bounds[-1] = en
@@ -39,10 +40,14 @@ def main():
                 bounds.append(en)
             last = en
     t0, t1 = bounds[-1 - nwin], bounds[-1]
-    tot, names = {}, {}
-    for st, en, name in rows:
+    tot, names, shapes = {}, {}, {}
+    for st, en, name, grid in rows:
         if st < t0 or en > t1:
             continue
+        if any(k in name for k in ("skp_wino", "skp_conv_s2", "skp_fa2_", "skp_self_attn", "skp_attn_map", "skp_map_", "Cijk")):
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:70]
+            sh = shapes.setdefault((short, grid), [0.0, 0])
+            sh[0] += en - st; sh[1] += 1
         for cls, keys in CLASSES:
             if any(k in name for k in keys):
                 break
@@ -64,6 +69,11 @@ def main():
         print(f"top kernels in '{cls}':")
         for n, (ns, c) in sorted(names.get(cls, {}).items(), key=lambda kv: -kv[1][0])[:8]:
             print(f"  {ns / nwin / 1e6:7.2f} ms/step  {c / nwin:6.1f} calls/step  {n}")
+    print("\nper launch shape (kernel, grid threads): calls/step, average us, ms/step -- the rows `roofline.launch_us` of bench.py "
+          "can be checked against")
+    print("| kernel | grid | calls/step | avg us | ms/step |\n|---|---|---|---|---|")
+    for (n, grid), (ns, c) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:40]:
+        print(f"| {n} | {grid} | {c / nwin:.1f} | {ns / c / 1e3:.1f} | {ns / nwin / 1e6:.2f} |")
 
 
 if __name__ == "__main__":
