@@ -890,20 +890,24 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
     return skp_launch_status();
 }
 
-static bool fa2_fused_ok(int Bk, int B, int N, int Nk, int d) {
+static bool fa2_fused_ok(int Bk, int B, int H, int N, int Nk, int d) {
     const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
     if (e && e[0] == '0') return false;
     // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 64-wide: two per CU with the dS exchange laid over the
     // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: the same with
     // 48-query tiles (75.8 KB; 57 spilled registers): 0.42 -> 0.55 at N = 1024, 0.69 at N = 4096 (SKP_FA2_D80=1: the
     // 64-query form at one workgroup per CU, 0.52 / 0.64).
-    return (d == 40 || d == 64 || d == 80) && Bk == B && N == Nk && N >= 1024;   // the big self-attention layers
+    if (!((d == 40 || d == 64 || d == 80) && Bk == B && N == Nk && N >= 1024)) return false;   // the big self-attention layers
+    // the single-pass form keeps ceil(Nk / 128) copies of dQ as partials: O(B N^2 C / 128) floats (13 GB at SD-2.1 768^2,
+    // B = 16).  Past 2 GiB the two-kernel form (B*H*N floats of scratch) takes over.
+    const long long part = (long long)((Nk + 127) / 128) * B * N * (long long)H * d * 4;
+    return part <= (2ll << 30);
 }
 
 // bytes of scratch the backward needs: D = rowsum(dO * O) [B,H,N], plus the per-key-block dQ partials of the fused form
 int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     int64_t fl = (int64_t)B * H * N;
-    if (fa2_fused_ok(Bk, B, N, Nk, d)) fl += (int64_t)((Nk + 127) / 128) * B * N * H * d;
+    if (fa2_fused_ok(Bk, B, H, N, Nk, d)) fl += (int64_t)((Nk + 127) / 128) * B * N * H * d;
     return fl * (int64_t)sizeof(float);
 }
 
@@ -944,7 +948,7 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
     hipStream_t st = (hipStream_t)stream;
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
-    if (allow_fused && fa2_fused_ok(Bk, B, N, Nk, d)) {
+    if (allow_fused && fa2_fused_ok(Bk, B, H, N, Nk, d)) {
         if (d == 40) return fa2_launch_bwd_fused<40, 2, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
         if (d == 64) return fa2_launch_bwd_fused<64, 2, true, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
         { const char* e8 = getenv("SKP_FA2_D80"); if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st); }

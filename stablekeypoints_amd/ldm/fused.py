@@ -67,13 +67,9 @@ def _transformer_forward(m: Transformer2DModel):
     def forward(x, context=None):
         if not ops.group_norm_supported(x, m.norm.num_groups):
             return orig(x, context)
+        if not ops.layout_supported(x):
+            return orig(x, context)                  # the module's own forward knows both projection layouts
         h = ops.group_norm_silu(x, m.norm, silu=False)
-        if not ops.layout_supported(h):
-            b, c, hh, ww = x.shape
-            h = m.proj_in(h).permute(0, 2, 3, 1).reshape(b, hh * ww, -1)
-            for blk in m.transformer_blocks:
-                h = blk(h, context=context)
-            return m.proj_out(h.reshape(b, hh, ww, -1).permute(0, 3, 1, 2)) + x
         # token layout throughout: the 1x1 convolutions are nn.Linear over tokens (bias fused in the GEMM), the two
         # permutes are tiled transposes and the residual add rides on the way back
         t = ops.nchw_to_tokens(h)

@@ -934,9 +934,12 @@ _X3_CACHE = {}
 def _x3_planes(weight, transpose: bool):
     """bf16 (h, m, l) planes of a frozen [N, K] weight ([3][N][K]) or of its transpose ([3][K][N]).  Cached per storage
     address + shape (call sites pass fresh views such as `conv.weight.flatten(1)`), re-made when the version moves."""
+    import weakref
+    owner = weight._base if weight._base is not None else weight          # the Parameter behind a view such as .flatten(1)
     key = (weight.data_ptr(), tuple(weight.shape), weight.device, bool(transpose))
     hit = _X3_CACHE.get(key)
-    if hit is not None and hit[0] == weight._version:
+    # the entry is only valid for the tensor it was made from: a freed model's address can be handed to another weight
+    if hit is not None and hit[0] == weight._version and hit[2]() is owner:
         return hit[1]
     w = _dev(weight.detach(), "weight")
     n, k = w.shape
@@ -944,7 +947,7 @@ def _x3_planes(weight, transpose: bool):
     planes = torch.empty(3 * rows * cols, device=w.device, dtype=torch.bfloat16)
     N.check(N.lib().skp_gemm_x3_split_f32(w.data_ptr(), planes.data_ptr(), rows, cols, int(transpose), _stream()),
             "skp_gemm_x3_split_f32")
-    _X3_CACHE[key] = (weight._version, planes)
+    _X3_CACHE[key] = (weight._version, planes, weakref.ref(owner))
     return planes
 
 
