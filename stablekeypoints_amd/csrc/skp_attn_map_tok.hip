@@ -22,7 +22,9 @@
 //      VECTOR registers that are indexed with the wave-uniform source column (s_set_gpr_idx); a row leaving THAT window
 //      is complete for this band and is stored, 64 B per head.  Tap indices beyond the borders are PyTorch's
 //      clamp-on-access.  Pixels go in chunks of four whose taps / (lse, dot) / gradient values are requested while the
-//      previous chunk computes.  No atomics; LDS only in the opt-in staged form (SKP_MAP_STAGE=1: rows through LDS-DMA).
+//      previous chunk computes; up-res rows that read the same four source rows go through the sweep as a PAIR (shared
+//      column loads, window moves and indexed updates; four independent pixel cores per chunk).  No atomics, no LDS.
+//      (A form that staged the (lse, dot) / gradient rows through LDS by LDS-DMA measured 8-12 % slower and was removed.)
 //   3. skp_map_bwd_bands_kernel: rows touched by several bands (the 3-row halo) are summed in band order.  The sweep is
 //      latency-bound per wave, so launches are cut into enough bands to fill and refill every wave slot of the chip.
 #include "skp_common.h"
@@ -185,7 +187,6 @@ struct TokArgs {
     int NB, BH, NTG, HG, NTGB;     // bands, band height, 16-token groups, head groups, workgroups per token axis
     float inv_lh;
     unsigned tab_bytes;            // buffer size for the tap-table descriptor
-    int lds_buf, HS;               // staged rows: bytes per buffer / per head row of (lse, dot)
 };
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -201,24 +202,21 @@ __device__ __forceinline__ TapS skp_tap(i32x4 rs, int idx) {
 }
 __device__ __forceinline__ int skp_tap_i0(i32x4 rs, int idx) { return skp_sbuf_load_x1(rs, idx * 32 + 16, 0); }
 
-typedef __attribute__((address_space(3))) void* skp_lds_ptr;
-typedef const __attribute__((address_space(1))) void* skp_glb_ptr;
 
 template <int N> struct SkpVec;
 template <> struct SkpVec<8> { typedef float type __attribute__((ext_vector_type(8))); };
 template <> struct SkpVec<16> { typedef float type __attribute__((ext_vector_type(16))); };
 template <> struct SkpVec<32> { typedef float type __attribute__((ext_vector_type(32))); };
 
-// STAGE: the (lse, dot) rows of the wave's four heads and the K gradient rows of its batch row go through wave-private
-// LDS, loaded one up-res row ahead by LDS-DMA (global_load_lds_dwordx4: no staging registers), so the pixel loop never
-// waits on HBM / L2 latency.  Needs R in {16, 32, 64, 128, 256} (whole rows per 1 KB DMA block).
 // SM: register class = width of the dz window rows (vector registers, indexed with the wave-uniform source column).
-// A workgroup = up to 8 waves = consecutive 16-token groups of ONE (batch row, layer, head group, band): they share the
-// staged rows (one barrier per up-res row; the DMA instructions are dealt round-robin to the waves).
-template <int SM, bool STAGE>
+// A workgroup = up to 8 waves = consecutive 16-token groups of ONE (batch row, layer, head group, band) (no barriers; the
+// grouping only keeps the waves that read the same (lse, dot) / gradient rows on one CU).
+// Up-res rows go in PAIRS that share their four source rows (R/s even: every even-odd pair does): the column loads, the
+// window moves and the indexed updates of the dz window serve both rows, and the two rows x two pixels of a chunk are
+// four independent pixel cores for the scheduler.
+template <int SM>
 __global__ __launch_bounds__(512, (SM <= 16 ? 2 : 1)) void skp_map_bwd_tok_kernel(TokArgs a) {
     typedef typename SkpVec<SM>::type vrow;
-    extern __shared__ __attribute__((aligned(16))) char smem_tok[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // everything derived from it is wave-uniform
     const int WPB = blockDim.x >> 6;
@@ -229,11 +227,11 @@ __global__ __launch_bounds__(512, (SM <= 16 ? 2 : 1)) void skp_map_bwd_tok_kerne
     const int m = task % a.NB;
     const int b = task / a.NB;
     const TokLayer& ly = a.ly[li];
-    const bool idle = tgb * WPB + wave >= a.NTG;               // a wave without a token group only keeps the barriers
-    const int tg = idle ? a.NTG - 1 : tgb * WPB + wave;
+    if (tgb * WPB + wave >= a.NTG) return;
+    const int tg = tgb * WPB + wave;
     const int hh = lane >> 4, t = tg * 16 + (lane & 15);
     const int h = hg * 4 + hh;
-    const bool live = h < a.H && t < a.T && !idle;             // pad tokens / heads beyond H: computed, stored as 0
+    const bool live = h < a.H && t < a.T;                      // pad tokens / heads beyond H: computed, stored as 0
     const int hA = h < a.H ? h : a.H - 1;
     const int R = a.R, s = ly.s, RR = R * R, K = a.K;
     const i32x4 rs_tab = skp_make_rsrc(ly.tab, a.tab_bytes);
@@ -245,45 +243,17 @@ __global__ __launch_bounds__(512, (SM <= 16 ? 2 : 1)) void skp_map_bwd_tok_kerne
         if ((int)a.sel[(size_t)b * K + k] == t) gk = k;
     const bool has_g = gk >= 0 && live;
     const bool any_g = __builtin_amdgcn_ballot_w64(has_g) != 0;          // this WAVE reads gradient rows
-    const int gslot = gk < 0 ? 0 : gk;
-    const float* __restrict__ Gp = a.G + ((size_t)b * K + gslot) * RR;
+    const float* __restrict__ Gp = a.G + ((size_t)b * K + (gk < 0 ? 0 : gk)) * RR;
     const float gscale = has_g ? a.inv_lh : 0.f;
 
     const int y0 = m * a.BH, y1 = (y0 + a.BH < R) ? y0 + a.BH : R;
+    if (y0 >= y1) return;
     float* __restrict__ outp = ly.out + (size_t)(b * a.H + hA) * ly.out_bh + (size_t)m * ly.out_band + t;
     int cur = skp_tap_i0(rs_tab, y0);                          // dz window rows: cur-1 .. cur+2
     const int rlo = cur - 1 < 0 ? 0 : cur - 1;                 // first row this band emits (partials are band-relative)
     const float keep = live ? 1.f : 0.f;
     const int sbase = ((b * a.H + hA) * s * s) * a.ldt * 4 + t * 4;        // byte offset of S[b,h,0,t]
     const int col_bytes = a.ldt * 4;
-
-    // ---- LDS staging (STAGE), shared by the workgroup ----
-    char* const lds_w = smem_tok;
-    const int HS = a.HS, GS = R * 4;
-    auto stage_row = [&](int y, int buf) {
-        if constexpr (STAGE) {
-            char* dst = lds_w + (size_t)buf * a.lds_buf;
-            const int per = (R * 8 + 1023) / 1024;             // DMA blocks per head row (HS = per KB + 32 B: bank offset)
-            const int lpr = R / 4, rpb = 64 / lpr;             // gradient rows: lanes per row, rows per DMA block
-            const int n_ld = 4 * per, n_all = n_ld + (K + rpb - 1) / rpb;
-            for (int i = wave; i < n_all; i += WPB) {          // instruction i of the row's DMA list
-                if (i < n_ld) {
-                    const int j = i / per, ch = i - j * per;
-                    const int hj = (hg * 4 + j < a.H) ? hg * 4 + j : a.H - 1;
-                    const f32x2* row = a.ld + ((size_t)(b * a.L + ly.l) * a.H + hj) * RR + (size_t)y * R;
-                    int px = (ch * 64 + lane) * 2;
-                    px = px < R ? px : 0;
-                    __builtin_amdgcn_global_load_lds((skp_glb_ptr)(row + px), (skp_lds_ptr)(dst + j * HS + ch * 1024), 16, 0, 0);
-                } else {
-                    const int gq = i - n_ld;
-                    int k = gq * rpb + lane / lpr;
-                    k = k < K ? k : K - 1;
-                    const float* src = a.G + ((size_t)b * K + k) * RR + (size_t)y * R + (lane % lpr) * 4;
-                    __builtin_amdgcn_global_load_lds((skp_glb_ptr)src, (skp_lds_ptr)(dst + 4 * HS + gq * 1024), 16, 0, 0);
-                }
-            }
-        }
-    };
 
     vrow win0 = 0.f, win1 = 0.f, win2 = 0.f, win3 = 0.f;       // dz rows cur-1 .. cur+2, indexed by the source column
 
@@ -296,25 +266,20 @@ __global__ __launch_bounds__(512, (SM <= 16 ? 2 : 1)) void skp_map_bwd_tok_kerne
         }
     };
 
-    if (y0 < y1) stage_row(y0, y0 & 1);
-    for (int y = y0; y < y1; ++y) {
-        if (idle) {                                            // keeps the row barrier and its share of the DMA
-            if constexpr (STAGE) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (y + 1 < y1) stage_row(y + 1, (y + 1) & 1);
-            }
-            continue;
-        }
-        const TapS ty = skp_tap(rs_tab, y);
+    for (int y = y0; y < y1;) {
+        const TapS tya = skp_tap(rs_tab, y);
         const int ty_i0 = skp_tap_i0(rs_tab, y);
+        // the partner row: the next one when it reads the same four source rows, else a copy of this row with zero weight
+        const bool pair = y + 1 < y1 && skp_tap_i0(rs_tab, y + 1) == ty_i0;
+        const int yb = pair ? y + 1 : y;
+        TapS tyb = skp_tap(rs_tab, yb);
+        if (!pair) tyb = TapS{0.f, 0.f, 0.f, 0.f};
         while (cur < ty_i0) {                                  // slot 0 is complete for this band
             if (cur - 1 < 0) win1 += win0;                     // clamped row: belongs to the border row
             else emit_row(cur - 1, win0);
             win0 = win1; win1 = win2; win2 = win3; win3 = 0.f;
             ++cur;
         }
-        const float wy0 = ty.w0, wy1 = ty.w1, wy2 = ty.w2, wy3 = ty.w3;
         int voff[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { int v = cur - 1 + j; v = v < 0 ? 0 : (v > s - 1 ? s - 1 : v); voff[j] = sbase + v * s * col_bytes; }
@@ -323,86 +288,84 @@ __global__ __launch_bounds__(512, (SM <= 16 ? 2 : 1)) void skp_map_bwd_tok_kerne
 #pragma unroll
             for (int j = 0; j < 4; ++j) raw[j] = skp_buf_load_f32(rs_S, voff[j], c * col_bytes, 0);
         };
-        auto vcol = [&](const float (&raw)[4]) {
-            float v = wy0 * raw[0];
-            v = fmaf(wy1, raw[1], v); v = fmaf(wy2, raw[2], v); v = fmaf(wy3, raw[3], v);
+        auto vcol = [&](const float (&raw)[4], const TapS& w) {
+            float v = w.w0 * raw[0];
+            v = fmaf(w.w1, raw[1], v); v = fmaf(w.w2, raw[2], v); v = fmaf(w.w3, raw[3], v);
             return v;
         };
-        auto vadj = [&](int c, float v) {                      // vertical adjoint of one finished source column
+        auto vadj = [&](int c, float va, float vb) {           // vertical adjoint of one finished source column, both rows
             c = c < 0 ? 0 : (c > s - 1 ? s - 1 : c);           // PyTorch clamps tap indices on access
-            win0[c] = fmaf(wy0, v, win0[c]); win1[c] = fmaf(wy1, v, win1[c]);
-            win2[c] = fmaf(wy2, v, win2[c]); win3[c] = fmaf(wy3, v, win3[c]);
+            win0[c] += fmaf(tya.w0, va, tyb.w0 * vb); win1[c] += fmaf(tya.w1, va, tyb.w1 * vb);
+            win2[c] += fmaf(tya.w2, va, tyb.w2 * vb); win3[c] += fmaf(tya.w3, va, tyb.w3 * vb);
         };
         // column window: source columns ccur-1 .. ccur+2 (clamped on access); it starts at the first pixel's position
         int ccur = skp_tap_i0(rs_tab, 0);
-        float raw[4], raw1[4], raw2[4], vw[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float raw[4], raw1[4], raw2[4], vwa[4], vwb[4], acca[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
         vcol_load(ccur - 1, raw); vcol_load(ccur, raw1); vcol_load(ccur + 1, raw2);
-        if constexpr (STAGE) {
-            // my share of this row's DMA (issued a row ago) has landed and my LDS reads of the previous row have retired;
-            // after the barrier that holds for every wave, so the other buffer may be refilled.  The column loads waited
-            // on here are needed by the next instructions anyway.
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (y + 1 < y1) stage_row(y + 1, (y + 1) & 1);
-        }
-        vw[0] = vcol(raw); vw[1] = vcol(raw1); vw[2] = vcol(raw2);
+        vwa[0] = vcol(raw, tya); vwb[0] = vcol(raw, tyb);
+        vwa[1] = vcol(raw1, tya); vwb[1] = vcol(raw1, tyb);
+        vwa[2] = vcol(raw2, tya); vwb[2] = vcol(raw2, tyb);
         vcol_load(ccur + 2, raw);
-        vw[3] = vcol(raw);
-        vcol_load(ccur + 3, raw);                              // the column the next window position adds
-        const f32x2* __restrict__ ldrow = ldp + (size_t)y * R;
-        const float* __restrict__ grow = Gp + (size_t)y * R;
-        const char* lrow = lds_w + (size_t)(y & 1) * a.lds_buf + hh * HS;
-        const char* lg = lds_w + (size_t)(y & 1) * a.lds_buf + 4 * HS + gslot * GS;
-        // The pixels of a row go in chunks of four; a chunk's taps and window positions (scalar loads), (lse, dot) and
-        // gradient values are requested while the previous chunk computes.
-        TapS tn[4]; int in[4];
-        f32x2 ln[4];
-        float gn[4] = {0.f, 0.f, 0.f, 0.f};
+        vwa[3] = vcol(raw, tya); vwb[3] = vcol(raw, tyb);
+        vcol_load(ccur + 3, raw);                              // the columns the next two window positions add
+        vcol_load(ccur + 4, raw1);
+        const f32x2* __restrict__ ldra = ldp + (size_t)y * R;
+        const f32x2* __restrict__ ldrb = ldp + (size_t)yb * R;
+        const float* __restrict__ gra = Gp + (size_t)y * R;
+        const float* __restrict__ grb = Gp + (size_t)yb * R;
+        // Pixels go in chunks of two; a chunk's taps and window positions (scalar loads), (lse, dot) and gradient values of
+        // both rows are requested while the previous chunk computes.
+        TapS tn[2]; int in[2];
+        f32x2 lna[2], lnb[2];
+        float gna[2] = {0.f, 0.f}, gnb[2] = {0.f, 0.f};
         auto chunk_load = [&](int xc) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 tn[j] = skp_tap(rs_tab, xc + j);               // past the row end: table slack, never used
                 in[j] = skp_tap_i0(rs_tab, xc + j);
-                if constexpr (STAGE) {
-                    ln[j] = *(const f32x2*)(lrow + (xc + j) * 8);
-                    if (any_g) gn[j] = *(const float*)(lg + (xc + j) * 4);
-                } else {
-                    const int xi = xc + j < R ? xc + j : R - 1;
-                    ln[j] = ldrow[xi];
-                    if (any_g) gn[j] = has_g ? grow[xi] : 0.f;
-                }
+                const int xi = xc + j < R ? xc + j : R - 1;
+                lna[j] = ldra[xi]; lnb[j] = ldrb[xi];
+                if (any_g) { gna[j] = has_g ? gra[xi] : 0.f; gnb[j] = has_g ? grb[xi] : 0.f; }
             }
         };
         chunk_load(0);
-        for (int x = 0; x < R; x += 4) {
-            TapS tc[4]; int ic[4]; f32x2 lc[4]; float gc[4];
+        for (int x = 0; x < R; x += 2) {
+            TapS tc[2]; int ic[2]; f32x2 lca[2], lcb[2]; float gca[2], gcb[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { tc[j] = tn[j]; ic[j] = in[j]; lc[j] = ln[j]; gc[j] = gn[j]; }
-            if (x + 4 < R) chunk_load(x + 4);
+            for (int j = 0; j < 2; ++j) { tc[j] = tn[j]; ic[j] = in[j]; lca[j] = lna[j]; lcb[j] = lnb[j]; gca[j] = gna[j]; gcb[j] = gnb[j]; }
+            if (x + 2 < R) chunk_load(x + 2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 if (x + j < R) {
-                    while (ccur < ic[j]) {                     // the window moves on: column ccur-1 is complete for this row
-                        vadj(ccur - 1, acc[0]);
-                        acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = acc[3]; acc[3] = 0.f;
-                        vw[0] = vw[1]; vw[1] = vw[2]; vw[2] = vw[3]; vw[3] = vcol(raw);
+                    while (ccur < ic[j]) {                     // the window moves on: column ccur-1 is complete for these rows
+                        vadj(ccur - 1, acca[0], accb[0]);
+                        acca[0] = acca[1]; acca[1] = acca[2]; acca[2] = acca[3]; acca[3] = 0.f;
+                        accb[0] = accb[1]; accb[1] = accb[2]; accb[2] = accb[3]; accb[3] = 0.f;
+                        vwa[0] = vwa[1]; vwa[1] = vwa[2]; vwa[2] = vwa[3]; vwa[3] = vcol(raw, tya);
+                        vwb[0] = vwb[1]; vwb[1] = vwb[2]; vwb[2] = vwb[3]; vwb[3] = vcol(raw, tyb);
                         ++ccur;
-                        vcol_load(ccur + 3, raw);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) raw[q] = raw1[q];
+                        vcol_load(ccur + 4, raw1);             // two positions ahead
                     }
-                    float zu = tc[j].w0 * vw[0];
-                    zu = fmaf(tc[j].w1, vw[1], zu); zu = fmaf(tc[j].w2, vw[2], zu); zu = fmaf(tc[j].w3, vw[3], zu);
-                    const float pr = __builtin_amdgcn_exp2f(zu - lc[j][0]);
-                    const float d = pr * fmaf(gc[j], gscale, -lc[j][1]);
-                    acc[0] = fmaf(tc[j].w0, d, acc[0]); acc[1] = fmaf(tc[j].w1, d, acc[1]);
-                    acc[2] = fmaf(tc[j].w2, d, acc[2]); acc[3] = fmaf(tc[j].w3, d, acc[3]);
+                    float za = tc[j].w0 * vwa[0], zb = tc[j].w0 * vwb[0];
+                    za = fmaf(tc[j].w1, vwa[1], za); zb = fmaf(tc[j].w1, vwb[1], zb);
+                    za = fmaf(tc[j].w2, vwa[2], za); zb = fmaf(tc[j].w2, vwb[2], zb);
+                    za = fmaf(tc[j].w3, vwa[3], za); zb = fmaf(tc[j].w3, vwb[3], zb);
+                    const float pa = __builtin_amdgcn_exp2f(za - lca[j][0]), pb = __builtin_amdgcn_exp2f(zb - lcb[j][0]);
+                    const float da = pa * fmaf(gca[j], gscale, -lca[j][1]), db = pb * fmaf(gcb[j], gscale, -lcb[j][1]);
+                    acca[0] = fmaf(tc[j].w0, da, acca[0]); accb[0] = fmaf(tc[j].w0, db, accb[0]);
+                    acca[1] = fmaf(tc[j].w1, da, acca[1]); accb[1] = fmaf(tc[j].w1, db, accb[1]);
+                    acca[2] = fmaf(tc[j].w2, da, acca[2]); accb[2] = fmaf(tc[j].w2, db, accb[2]);
+                    acca[3] = fmaf(tc[j].w3, da, acca[3]); accb[3] = fmaf(tc[j].w3, db, accb[3]);
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vadj(ccur - 1 + i, acc[i]);          // the four columns still in the window
+        for (int i = 0; i < 4; ++i) vadj(ccur - 1 + i, acca[i], accb[i]);        // the four columns still in the window
+        y = yb + 1;
     }
-    if (idle || y0 >= y1) return;
     // flush: rows beyond the bottom border belong to row s-1, rows above the top border to row 0
     if (cur + 2 > s - 1) win2 += win3;
     if (cur + 1 > s - 1) win1 += win2;
@@ -484,18 +447,9 @@ extern "C" int64_t skp_attn_map_bwd_sparse_workspace(const int* s, int L, int B,
 }
 
 template <int SM>
-static int skp_tok_launch(TokArgs& a, bool stage, size_t lds, int wpb, hipStream_t st) {
+static int skp_tok_launch(TokArgs& a, int wpb, hipStream_t st) {
     const unsigned nblk = (unsigned)((long)a.B * a.NB * a.nl * a.HG * a.NTGB);
-    if (stage) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)skp_map_bwd_tok_kernel<SM, true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL((skp_map_bwd_tok_kernel<SM, true>), dim3(nblk), dim3(64 * wpb), lds, st, a);
-    } else {
-        hipLaunchKernelGGL((skp_map_bwd_tok_kernel<SM, false>), dim3(nblk), dim3(64 * wpb), 0, st, a);
-    }
+    hipLaunchKernelGGL((skp_map_bwd_tok_kernel<SM>), dim3(nblk), dim3(64 * wpb), 0, st, a);
     return 0;
 }
 
@@ -544,18 +498,8 @@ extern "C" int skp_attn_map_bwd_sparse_f32(const float* const* S, float* const* 
     a.NTG = nt / 16; a.HG = (H + 3) / 4;
     a.inv_lh = 1.0f / (float)(L * H);
     a.tab_bytes = (unsigned)tab_bytes;
-    // LDS staging of the (lse, dot) rows and the K gradient rows: whole rows per 1 KB DMA block
-    bool stage = (R == 16 || R == 32 || R == 64 || R == 128 || R == 256);
-    a.HS = ((R * 8 + 1023) / 1024) * 1024 + 32;                // + 32 B: the four heads' rows start 8 banks apart
-    const int rpb = stage ? 256 / R : 1;
-    a.lds_buf = 4 * a.HS + ((K + rpb - 1) / rpb) * 1024 + 32;
-    size_t lds = 2 * (size_t)a.lds_buf;                        // two rows in flight, shared by the workgroup's waves
-    if (lds > 64 * 1024) stage = false;
     const int wpb = a.NTG < 8 ? a.NTG : 8;
     a.NTGB = (a.NTG + wpb - 1) / wpb;
-    // measured (profiles/r03_map_kernels.md): the staged form is 8-12 % SLOWER than per-lane loads with a one-chunk prefetch
-    // (the row barrier costs more than the L2 latency it hides) => opt-in for experiments only
-    { const char* e = getenv("SKP_MAP_STAGE"); if (!(e && e[0] == '1')) stage = false; }
     BandArgs r{};
     r.B = B; r.H = H; r.T = T; r.R = R; r.NT = nt; r.ldt = ldt;
     long n4max = 0;
@@ -586,9 +530,7 @@ extern "C" int skp_attn_map_bwd_sparse_f32(const float* const* S, float* const* 
             }
         }
         if (!a.nl) continue;
-        int rc = cls == 0 ? skp_tok_launch<8>(a, stage, stage ? lds : 0, wpb, st)
-               : cls == 1 ? skp_tok_launch<16>(a, stage, stage ? lds : 0, wpb, st)
-                          : skp_tok_launch<32>(a, stage, stage ? lds : 0, wpb, st);
+        int rc = cls == 0 ? skp_tok_launch<8>(a, wpb, st) : cls == 1 ? skp_tok_launch<16>(a, wpb, st) : skp_tok_launch<32>(a, wpb, st);
         if (rc) return rc;
     }
     // 3. band partials -> dS
