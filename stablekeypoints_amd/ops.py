@@ -144,7 +144,7 @@ def _map_bwd(S, dS, sides, B, H, T, R, dM, lse):
 
 
 # Which map backward the fused step takes.  "auto": the sparse token-major sweep when T > 128 (one pass instead of token
-# groups x two passes: 2.9 vs 7.9 ms at T = 500, B = 8), the dense-gradient kernels for T <= 128 (0.54 vs 0.72 ms at
+# groups x two passes: 2.4 vs 7.9 ms at T = 500, B = 8), the dense-gradient kernels for T <= 128 (0.53 vs 0.64 ms at
 # T = 77: there the sweep has too few token groups to fill the chip without 8-row bands; profiles/r03_map_kernels.md);
 # "sparse" / "dense" force one of them (A/B runs, tests).
 MAP_BWD_MODE = os.environ.get("SKP_MAP_BWD", "auto")
