@@ -28,7 +28,8 @@ struct FA2 {
     static constexpr int LDK = D + 4;           // LDS row stride (floats): conflict-free b64 K reads and b32 V reads for D = 40/64/80
     static constexpr int D8 = D / 8;            // ds_read_b64 per key row = two k-steps each
     static constexpr int CT = (D + 15) / 16;    // 16-channel output tiles
-    static constexpr int KT = 64;               // keys per LDS tile
+    static constexpr int KT = D > 128 ? 32 : 64;   // keys per LDS tile (160-wide heads: four double-buffered 64-row tiles exceed the LDS)
+    static constexpr int NKT = KT / 16;         // 16-row blocks per tile
     static constexpr int TILE = KT * LDK;       // floats per staged matrix
     static constexpr int Q4 = D / 4;            // float4 per row
     static constexpr int U = (KT * Q4 + 255) / 256;   // float4 per thread and staged matrix
@@ -267,16 +268,16 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
                 fa2_fetch_otf<D>(vr, vg + (size_t)(kt0 + F::KT) * C, Nk - kt0 - F::KT, C, tid);
             }
         }
-        f32x4 s[4][NQT];
+        f32x4 s[F::NKT][NQT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < F::NKT; ++kt)
 #pragma unroll
             for (int nt = 0; nt < NQT; ++nt) s[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        fa2_rowdot<D, 4, NQT>(Ks, qf, s, i16, g);
+        fa2_rowdot<D, F::NKT, NQT>(Ks, qf, s, i16, g);
         if (kt0 + F::KT > Nk) {                                 // ragged last tile (uniform branch)
             const int left = Nk - kt0;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < F::NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (16 * kt + 4 * g + r >= left) {
@@ -288,14 +289,14 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
         for (int nt = 0; nt < NQT; ++nt) {                      // one query block after the other: the next block's max
             float tm = fmaxf(fmaxf(s[0][nt][0], s[0][nt][1]), fmaxf(s[0][nt][2], s[0][nt][3]));   // reduction overlaps this block's exps
 #pragma unroll
-            for (int kt = 1; kt < 4; ++kt) tm = fmaxf(tm, fmaxf(fmaxf(s[kt][nt][0], s[kt][nt][1]), fmaxf(s[kt][nt][2], s[kt][nt][3])));
+            for (int kt = 1; kt < F::NKT; ++kt) tm = fmaxf(tm, fmaxf(fmaxf(s[kt][nt][0], s[kt][nt][1]), fmaxf(s[kt][nt][2], s[kt][nt][3])));
             tm = fa2_max4(tm);
             const float mn = fmaxf(mrun[nt], tm);
             const float alpha = __builtin_amdgcn_exp2f(mrun[nt] - mn);     // first tile: exp2(-inf) = 0
             mrun[nt] = mn;
             float rs = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < F::NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s[kt][nt][r] = __builtin_amdgcn_exp2f(s[kt][nt][r] - mn);
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) o[ct][nt] *= alpha;
         }
-        fa2_colacc<D, 4, NQT>(Vs, s, o, i16, g);
+        fa2_colacc<D, F::NKT, NQT>(Vs, s, o, i16, g);
         if (more) {
             float* nb = smem + (cur ^ 1) * 2 * F::TILE;
             if (PRE) { fa2_put<D>(nb, kr, stg); fa2_put<D>(nb + F::TILE, vr, stg); }
@@ -403,17 +404,17 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
             fa2_stage_in<D, PRE>(kr, kg, C, kt0 + F::KT, Nk, stg, tid);
             fa2_stage_in<D, PRE>(vr, vg, C, kt0 + F::KT, Nk, stg, tid);
         }
-        f32x4 s[4][NQT], dp[4][NQT];
+        f32x4 s[F::NKT][NQT], dp[F::NKT][NQT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < F::NKT; ++kt)
 #pragma unroll
             for (int nt = 0; nt < NQT; ++nt) { s[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        fa2_rowdot<D, 4, NQT>(Ks, qf, s, i16, g);
-        fa2_rowdot<D, 4, NQT>(Vs, dof, dp, i16, g);
+        fa2_rowdot<D, F::NKT, NQT>(Ks, qf, s, i16, g);
+        fa2_rowdot<D, F::NKT, NQT>(Vs, dof, dp, i16, g);
         if (kt0 + F::KT > Nk) {                                 // ragged last tile: keys beyond the end contribute nothing
             const int left = Nk - kt0;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < F::NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (16 * kt + 4 * g + r >= left) {
@@ -422,13 +423,13 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
                     }
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < F::NKT; ++kt)
 #pragma unroll
             for (int nt = 0; nt < NQT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     s[kt][nt][r] = __builtin_amdgcn_exp2f(s[kt][nt][r] - lse2[nt]) * (dp[kt][nt][r] - dsum[nt]);     // dS
-        fa2_colacc<D, 4, NQT>(Ks, s, dqa, i16, g);
+        fa2_colacc<D, F::NKT, NQT>(Ks, s, dqa, i16, g);
         if (more) {
             float* nb = smem + (cur ^ 1) * 2 * F::TILE;
             fa2_stage_out<D, PRE>(nb, kr, stg, tid);
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
                                                                     float* __restrict__ dk, float* __restrict__ dv, int H, int N,
                                                                     int Nk, int kvb, float scale) {
     using F = FA2<D>;
-    constexpr int BUF = 2 * F::TILE + 128;
+    constexpr int BUF = 2 * F::TILE + 2 * F::KT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y, C = H * D;
@@ -489,12 +490,12 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) { dka[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    // per-row statistics of a query tile: thread tid < 64 carries lse2, 64 <= tid < 128 carries D
+    // per-row statistics of a query tile: thread tid < KT carries lse2, KT <= tid < 2 KT carries D
     auto fetch_stats = [&](int q0) -> float {
-        const int i = tid & 63, n = q0 + i;
-        if (tid >= 128) return 0.f;
-        if (n >= N) return tid < 64 ? INFINITY : 0.f;            // missing rows: lse2 = +inf => their P is exactly 0
-        return tid < 64 ? lse[soff + n] * SKP_LOG2E : Dbuf[soff + n];
+        const int i = tid & (F::KT - 1), n = q0 + i;
+        if (tid >= 2 * F::KT) return 0.f;
+        if (n >= N) return tid < F::KT ? INFINITY : 0.f;         // missing rows: lse2 = +inf => their P is exactly 0
+        return tid < F::KT ? lse[soff + n] * SKP_LOG2E : Dbuf[soff + n];
     };
     FA2Stage<D> stg;
     if (PRE) stg.init(C, tid);
@@ -504,32 +505,32 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
     fa2_stage_in<D, PRE>(dr, dog, C, 0, N, stg, tid);
     fa2_stage_out<D, PRE>(smem, qr, stg, tid);
     fa2_stage_out<D, PRE>(smem + F::TILE, dr, stg, tid);
-    if (tid < 128) smem[2 * F::TILE + tid] = st;
+    if (tid < 2 * F::KT) smem[2 * F::TILE + tid] = st;
     __syncthreads();
 
     int cur = 0;
     for (int q0 = 0; q0 < N; q0 += F::KT) {
         const float* Qs = smem + cur * BUF;
         const float* dOs = Qs + F::TILE;
-        const float* Ls = dOs + F::TILE;                        // lse2[64] | D[64]
+        const float* Ls = dOs + F::TILE;                        // lse2[KT] | D[KT]
         const bool more = q0 + F::KT < N;
         if (more) {
             st = fetch_stats(q0 + F::KT);
             fa2_stage_in<D, PRE>(qr, qg, C, q0 + F::KT, N, stg, tid);
             fa2_stage_in<D, PRE>(dr, dog, C, q0 + F::KT, N, stg, tid);
         }
-        f32x4 s[4][NTT], dp[4][NTT];
+        f32x4 s[F::NKT][NTT], dp[F::NKT][NTT];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < F::NKT; ++nt)
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        fa2_rowdot<D, 4, NTT>(Qs, kf, s, i16, g);               // S[n][t]: rows = staged queries, lane = key
-        fa2_rowdot<D, 4, NTT>(dOs, vf, dp, i16, g);             // dP[n][t] = dO[n] . V[t]
+        fa2_rowdot<D, F::NKT, NTT>(Qs, kf, s, i16, g);               // S[n][t]: rows = staged queries, lane = key
+        fa2_rowdot<D, F::NKT, NTT>(dOs, vf, dp, i16, g);             // dP[n][t] = dO[n] . V[t]
         // rows beyond N (ragged last tile) were staged as zeros with lse2 = +inf  =>  P = exp2(0 - inf) = 0, dS = 0
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < F::NKT; ++nt) {
             const f32x4 l4 = *(const f32x4*)(Ls + 16 * nt + 4 * g);
-            const f32x4 d4 = *(const f32x4*)(Ls + 64 + 16 * nt + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(Ls + F::KT + 16 * nt + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -539,13 +540,13 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
                     dp[nt][tt][r] = pr * (dp[nt][tt][r] - d4[r]);        // dS
                 }
         }
-        fa2_colacc<D, 4, NTT>(dOs, s, dva, i16, g);             // dV^T[c][t] += sum_n dO[n][c] P[n][t]
-        fa2_colacc<D, 4, NTT>(Qs, dp, dka, i16, g);             // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
+        fa2_colacc<D, F::NKT, NTT>(dOs, s, dva, i16, g);             // dV^T[c][t] += sum_n dO[n][c] P[n][t]
+        fa2_colacc<D, F::NKT, NTT>(Qs, dp, dka, i16, g);             // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
         if (more) {
             float* nb = smem + (cur ^ 1) * BUF;
             fa2_stage_out<D, PRE>(nb, qr, stg, tid);
             fa2_stage_out<D, PRE>(nb + F::TILE, dr, stg, tid);
-            if (tid < 128) nb[2 * F::TILE + tid] = st;
+            if (tid < 2 * F::KT) nb[2 * F::TILE + tid] = st;
         }
         __syncthreads();
         cur ^= 1;
@@ -861,6 +862,8 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
         case 80:
             if (opt == 4) FA2_FWD(80, 2, 2, 4);
             FA2_FWD(80, 2, 2, 0);
+        case 160:                                               // 16^2 layers (N = 256): 16 queries per wave, 32-key tiles
+            FA2_FWD(160, 1, 1, 0);
         default: return -100;
     }
 #undef FA2_FWD
@@ -871,7 +874,7 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
                           const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk, int kvb,
                           float scale, hipStream_t st) {
     using F = FA2<D>;
-    const size_t lds_q = (size_t)4 * F::TILE * sizeof(float), lds_kv = (size_t)2 * (2 * F::TILE + 128) * sizeof(float);
+    const size_t lds_q = (size_t)4 * F::TILE * sizeof(float), lds_kv = (size_t)2 * (2 * F::TILE + 2 * F::KT) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_dq_kernel<D, NQ, MINWQ, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
@@ -969,6 +972,8 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
             if (variant == 1) FA2_BWD(80, 1, 2, 1, 2, false);
             if (variant == 2) FA2_BWD(80, 2, 1, 2, 1, true);
             FA2_BWD(80, 2, 1, 2, 1, false);
+        case 160:
+            FA2_BWD(160, 1, 1, 1, 1, false);
         default: return -100;
     }
 #undef FA2_BWD
