@@ -42,7 +42,7 @@ struct S2Args {
     int B, Cin, Cout, H, W, OH, OW, pad;
     int tilesX, tilesPerImg;
     unsigned x_bytes, u_bytes, y_bytes;
-    float* stats;            // optional [B][Cout][tilesPerImg][2] = {sum y, sum y^2} per 8x16-pixel tile (next GroupNorm), or null
+    float* stats;            // optional [B][Cout][tilesPerImg][2] = {mean, sum (y - mean)^2} per 8x16-pixel tile (next GroupNorm), or null
 };
 
 __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
@@ -144,19 +144,32 @@ __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
             const bool cok = co < a.Cout;
             const float bv = skp_buf_load_f32(brs, cok ? co * 4 : SKP_OOB, 0, 0);
             const int base = ((b * a.Cout + co) * a.OH + oy0) * a.OW + ox0 + i16;
-            float s1 = 0.f, s2 = 0.f;
+            float vals[S2_TOH];
 #pragma unroll
             for (int nt = 0; nt < S2_TOH; ++nt) {
                 const float v = acc[mt][nt][r] + bv;
                 skp_buf_store_f32(v, yrs, cok ? (base + nt * a.OW) * 4 : SKP_OOB, 0, 0);
-                s1 += v; s2 += v * v;
+                vals[nt] = v;
             }
-            if (a.stats) {                                       // uniform branch: tile sums over the 16 pixel lanes
+            if (a.stats) {                                       // uniform branch: {mean, sum (y - mean)^2} of the 8x16-pixel tile
+                // lane: about its first value; the 16 pixel lanes merge pairwise with equal counts (Chan et al.)
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                for (int nt = 1; nt < S2_TOH; ++nt) { const float d = vals[nt] - vals[0]; s1 += d; s2 += d * d; }
+                const float dm = s1 * (1.0f / S2_TOH);
+                float mean = vals[0] + dm, m2 = s2 - s1 * dm;
+                float cnt = (float)S2_TOH;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const float om = __shfl_xor(mean, o, 64), o2 = __shfl_xor(m2, o, 64);
+                    const float d = om - mean;
+                    m2 = m2 + o2 + d * d * (cnt * 0.5f);
+                    mean = 0.5f * (mean + om);
+                    cnt *= 2.0f;
+                }
                 if (i16 == 0 && cok) {
                     float* dst = a.stats + (((size_t)b * a.Cout + co) * a.tilesPerImg + rem) * 2;
-                    dst[0] = s1; dst[1] = s2;
+                    dst[0] = mean; dst[1] = m2;
                 }
             }
         }
@@ -181,7 +194,7 @@ extern "C" int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias
     return s2_run(x, U, bias, y, nullptr, B, Cin, Cout, H, W, pad, stream);
 }
 
-// as above + stats [B][Cout][(H/16)*(W/32)][2]: {sum, sum of squares} of y over each 8x16-pixel output tile
+// as above + stats [B][Cout][(H/16)*(W/32)][2]: {mean, sum of squared deviations} of y over each 8x16-pixel output tile
 extern "C" int skp_conv3x3_s2_stats_f32(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin,
                                         int Cout, int H, int W, int pad, void* stream) {
     if (!stats) return SKP_E_BADARG;

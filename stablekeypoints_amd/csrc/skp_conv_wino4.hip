@@ -79,29 +79,36 @@ struct Wino4Args {
     int ntb, ncg, tb_per_xcd;   // tile blocks, channel groups, tile blocks per XCD band (0: unit-grouped order)
     int splits;                 // K splits
     size_t y_split_stride;
-    float* stats;               // optional [B][Cout][tilesPerImg/16][2] = {sum y, sum y^2} per 16-tile block (next GroupNorm), or null
+    float* stats;               // optional [B][Cout][tilesPerImg/16][2] = {mean, sum (y - mean)^2} per 16-tile block (next GroupNorm), or null
     int sblk;                   // 16-tile blocks per image
     const float* gncoef;        // GNF kernels: [B][Cin][2] = (scale, shift) of the GroupNorm(+offset) in front of this convolution
 };
 
-// Block statistics without register pressure: every lane parks the sum / sum of squares of its 4x4 outputs in the (idle)
-// LDS stage buffers, [slot][64 lanes] float2; after the epilogue 128 threads add the 16 tile lanes of one (channel, block)
-// each in fixed order and store {sum y, sum y^2}.
+// Block statistics without register pressure: every lane parks {mean, M2 = sum (y - mean)^2} of its 4x4 outputs -- taken
+// about the lane's first value, so a channel whose mean dwarfs its spread loses nothing to cancellation -- in the (idle) LDS
+// stage buffers, [slot][64 lanes] float2; after the epilogue 128 threads merge the 16 tile lanes of one (channel, block) each
+// in fixed order (equal counts: mean = average of means, M2 = sum M2_i + 16 sum (mean_i - mean)^2) and store {mean, M2}.
 __device__ __forceinline__ void w4_park_stats(f32x2* sbuf, int slot, int lane, const f32x4 (&o)[4], bool ok) {
+    const float K = o[0][0];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int oy = 0; oy < 4; ++oy)
 #pragma unroll
-        for (int ox = 0; ox < 4; ++ox) { s1 += o[oy][ox]; s2 += o[oy][ox] * o[oy][ox]; }
-    sbuf[slot * 64 + lane] = ok ? f32x2{s1, s2} : f32x2{0.f, 0.f};
+        for (int ox = 0; ox < 4; ++ox) { const float d = o[oy][ox] - K; s1 += d; s2 += d * d; }
+    const float dm = s1 * (1.0f / 16.0f);
+    sbuf[slot * 64 + lane] = ok ? f32x2{K + dm, s2 - s1 * dm} : f32x2{0.f, 0.f};
 }
 __device__ __forceinline__ void w4_store_stats(const Wino4Args& a, const f32x2* sbuf, int slot, int kq, int tile_first, int co) {
-    f32x2 t = {0.f, 0.f};
+    float msum = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += sbuf[slot * 64 + kq * 16 + i];
+    for (int i = 0; i < 16; ++i) { const f32x2 t = sbuf[slot * 64 + kq * 16 + i]; msum += t[0]; m2 += t[1]; }
+    const float mean = msum * (1.0f / 16.0f);
+    float dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = sbuf[slot * 64 + kq * 16 + i][0] - mean; dev += d * d; }
     if (co < a.Cout && tile_first < a.nTiles) {
         const int b = tile_first / a.tilesPerImg, blk = (tile_first - b * a.tilesPerImg) >> 4;
-        *(f32x2*)(a.stats + (((size_t)b * a.Cout + co) * a.sblk + blk) * 2) = t;
+        *(f32x2*)(a.stats + (((size_t)b * a.Cout + co) * a.sblk + blk) * 2) = f32x2{mean, m2 + 16.0f * dev};
     }
 }
 

@@ -61,33 +61,46 @@ __device__ __forceinline__ void skp_gn_finalize(const float* partial, int row, i
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// Statistics from the block sums a producing convolution left behind (skp_conv3x3_f4_stats_f32 / skp_conv3x3_s2_stats_f32):
-// bs[n][c][blk] = {sum y, sum y^2} over `pix` pixels each.  One workgroup per (sample, group); fp64 combine; the
-// per-(sample, channel) offset is folded in analytically: sum (y+o) = s + cnt o, sum (y+o)^2 = q + 2 o s + cnt o^2.
+// Statistics from the block moments a producing convolution left behind (skp_conv3x3_f4_stats_f32 / skp_conv3x3_s2_stats_f32):
+// bs[n][c][blk] = {mean, M2 = sum (y - mean)^2} over `pix` pixels each.  One workgroup per (sample, group); the blocks are
+// merged in fp64 (group mean first, then M2 = sum [M2_b + pix (mean_b + o_c - mean)^2]: no difference of large sums
+// anywhere); the per-(sample, channel) offset only shifts a block's mean.
 __global__ __launch_bounds__(256) void skp_gn_from_blocks_kernel(GNArgs a, const float* __restrict__ bs, int nblk, int pix,
                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double red[2][4];
+    __shared__ double red[4];
+    __shared__ double gmean;
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
-    double s1 = 0.0, s2 = 0.0;
+    auto block_sum = [&](double v) {                           // fixed order: wave butterflies, then the four waves
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    double s1 = 0.0;
+    for (int e = tid; e < Cg * nblk; e += 256) {
+        const int cl = e / nblk, blk = e - cl * nblk, c = g * Cg + cl;
+        const double o = a.off ? (double)a.off[(size_t)n * a.C + c] : 0.0;
+        s1 += (double)bs[(((size_t)n * a.C + c) * nblk + blk) * 2] + o;
+    }
+    const double m = block_sum(s1) / (double)(Cg * nblk);      // equal block sizes: the mean of the block means
+    if (tid == 0) gmean = m;
+    __syncthreads();
+    double m2 = 0.0;
     for (int e = tid; e < Cg * nblk; e += 256) {
         const int cl = e / nblk, blk = e - cl * nblk, c = g * Cg + cl;
         const float* p = bs + (((size_t)n * a.C + c) * nblk + blk) * 2;
         const double o = a.off ? (double)a.off[(size_t)n * a.C + c] : 0.0;
-        const double s = p[0], q = p[1];
-        s1 += s + pix * o;
-        s2 += q + 2.0 * o * s + pix * o * o;
+        const double d = (double)p[0] + o - gmean;
+        m2 += (double)p[1] + (double)pix * d * d;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
-    __syncthreads();
+    const double t2 = block_sum(m2);
     if (tid == 0) {
-        const double t1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), t2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        const double m = t1 / (double)a.L;
-        double var = t2 / (double)a.L - m * m;
+        double var = t2 / (double)a.L;
         var = var < 0.0 ? 0.0 : var;
-        mean_out[row] = (float)m;
+        mean_out[row] = (float)gmean;
         rstd_out[row] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
 }

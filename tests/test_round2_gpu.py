@@ -467,9 +467,9 @@ def test_optimize_embedding_runs_on_sd2x_sdxl_trees(arch):
 
 
 def test_conv_epilogue_statistics_feed_group_norm(ops):
-    """GroupNorm statistics taken from the producing convolution's epilogue (block sums of the OUTPUT incl. bias / shortcut;
-    Winograd stride-1 forms and the stride-2 kernel) instead of a pass over the activation: block sums vs torch, and the
-    normalised result + input gradient vs the two-pass kernel and vs fp64."""
+    """GroupNorm statistics taken from the producing convolution's epilogue (block {mean, sum of squared deviations} of the
+    OUTPUT incl. bias / shortcut; Winograd stride-1 forms and the stride-2 kernel) instead of a pass over the activation:
+    block moments vs torch, and the normalised result + input gradient vs the two-pass kernel and vs fp64."""
     g = torch.Generator().manual_seed(41)
     seen = 0
     for (B, ci, co, H, W, with_res) in ((2, 32, 128, 32, 32, True), (2, 64, 64, 32, 64, False), (1, 128, 256, 64, 32, True),
@@ -489,8 +489,8 @@ def test_conv_epilogue_statistics_feed_group_norm(ops):
         seen += 1
         # blocks are 16 consecutive 4x4 tiles in tile-raster order
         t = y.reshape(B, co, H // 4, 4, W // 4, 4).permute(0, 1, 2, 4, 3, 5).reshape(B, co, nblk, 256).double()
-        torch.testing.assert_close(bs[..., 0].double(), t.sum(-1), rtol=1e-5, atol=1e-4)
-        torch.testing.assert_close(bs[..., 1].double(), (t * t).sum(-1), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(bs[..., 0].double(), t.mean(-1), rtol=1e-5, atol=1e-6)                     # block mean
+        torch.testing.assert_close(bs[..., 1].double(), ((t - t.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
         norm = torch.nn.GroupNorm(32, co, eps=1e-6).cuda()
         with torch.no_grad():
             norm.weight.copy_(torch.randn(co, generator=g)); norm.bias.copy_(torch.randn(co, generator=g))
@@ -517,8 +517,8 @@ def test_conv_epilogue_statistics_feed_group_norm(ops):
         bs, nblk, pix = y._skp_blocks
         assert (nblk, pix) == (4 * 2, 128)
         t = y.reshape(2, 64, 4, 8, 2, 16).permute(0, 1, 2, 4, 3, 5).reshape(2, 64, nblk, 128).double()
-        torch.testing.assert_close(bs[..., 0].double(), t.sum(-1), rtol=1e-5, atol=1e-4)
-        torch.testing.assert_close(bs[..., 1].double(), (t * t).sum(-1), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(bs[..., 0].double(), t.mean(-1), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bs[..., 1].double(), ((t - t.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
         norm = torch.nn.GroupNorm(32, 64, eps=1e-6).cuda()
         z = ops.group_norm_silu(y, norm)
         z_ref = ops.group_norm_silu(y.clone(), norm)
