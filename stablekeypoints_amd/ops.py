@@ -1056,23 +1056,38 @@ def conv3x3_s2_supported(x, weight) -> bool:
             and w % 32 == 0 and max(b * ci * h * w, b * co * (h // 2) * (w // 2), 9 * ci * co) * 4 < 2 ** 31)
 
 
+S2_BWD_OWN = os.environ.get("SKP_S2_BWD", "own") != "lib"      # A/B switch: "lib" = the library's backward-data
+
+
 class ConvS2Fn(torch.autograd.Function):
     """Stride-2 3x3 convolution of a frozen UNet Downsample2D whose INPUT needs a gradient: forward on the direct MFMA
-    kernel, input gradient through the library's backward-data (a polyphase form of the kernel is not built)."""
+    kernel.  Input gradient: the transposed stride-2 convolution is the stride-1 convolution of the ZERO-STUFFED output
+    gradient (dy_up[2i, 2j] = dy[i, j]) with the rotated, transposed filter -- i.e. the Winograd backward-data kernel of
+    the stride-1 layers on a dy_up of the input's size (three quarters of its taps multiply zeros, which costs what the
+    direct form's 4x multiplies would; no library call, no NCHW <-> NHWC transposes).  pad = 1 (UNet): out[i] reads
+    x[2i - 1 + k] => dx[y] = sum_k w[k] dy_up[y + 1 - k]; pad = 0 (asymmetric (0,1,0,1) extension): x[2i + k] =>
+    dy_up is shifted by one: dy_up[2i + 1, 2j + 1] = dy[i, j]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pad):
-        ctx.save_for_backward(weight)
+        ctx.weight = weight
         ctx.xshape, ctx.pad = tuple(x.shape), int(pad)
         return _conv3x3_s2_raw(x, weight, bias, pad, False)
 
     @staticmethod
     def backward(ctx, dy):
-        (w,) = ctx.saved_tensors
+        w = ctx.weight
+        b, c, h, wd = ctx.xshape
+        co = w.shape[0]
+        if S2_BWD_OWN and h % 2 == 0 and wd % 2 == 0 and conv3x3_wanted((b, co, h, wd), (c, co, 3, 3)):
+            dy = _dev(dy, "dy")
+            up = torch.zeros(b, co, h, wd, device=dy.device, dtype=torch.float32)
+            o = 0 if ctx.pad == 1 else 1
+            up[:, :, o::2, o::2] = dy
+            return _conv3x3_run(up, w, True, None, None, c), None, None, None
         if ctx.pad == 1:
             return torch.nn.grad.conv2d_input(ctx.xshape, w, dy.contiguous(), stride=2, padding=1), None, None, None
-        b, c, h, wd = ctx.xshape                                 # pad 0 = asymmetric (0,1,0,1) extension
-        dxp = torch.nn.grad.conv2d_input((b, c, h + 1, wd + 1), w, dy.contiguous(), stride=2, padding=0)
+        dxp = torch.nn.grad.conv2d_input((b, c, h + 1, wd + 1), w, dy.contiguous(), stride=2, padding=0)   # pad 0 = (0,1,0,1) extension
         return dxp[:, :, :h, :wd], None, None, None
 
 

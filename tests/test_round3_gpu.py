@@ -504,3 +504,28 @@ def test_epilogue_statistics_survive_a_large_channel_mean():
         ref = torch.nn.functional.silu(nd(y.detach().cpu().double()))
     print("large-mean norm: max abs err", (z.cpu().double() - ref).abs().max().item())
     torch.testing.assert_close(z.cpu().double(), ref, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("B,ci,co,H,W,pad", [(2, 64, 64, 32, 32, 1), (1, 32, 64, 32, 64, 0), (4, 320, 320, 64, 64, 1), (2, 64, 32, 16, 16, 1)])
+def test_stride2_conv_input_gradient_own_kernels_vs_fp64(B, ci, co, H, W, pad):
+    """Input gradient of the stride-2 3x3 convolution (UNet Downsample2D) = stride-1 Winograd backward-data kernel on the
+    zero-stuffed output gradient, against fp64 autograd of F.conv2d (both padding modes)."""
+    import torch.nn.functional as F
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, ci, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
+    b = torch.randn(co, generator=g).cuda()
+    if not ops.conv3x3_s2_supported(x, w):
+        pytest.skip("shape not served by the stride-2 kernel")
+    y = ops.conv3x3_s2(x, w, b, pad=pad)
+    wgt = torch.randn(y.shape, generator=g).cuda()
+    (y * wgt).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    xe = F.pad(xd, (0, 1, 0, 1)) if pad == 0 else xd
+    yd = F.conv2d(xe, w.double(), b.double(), stride=2, padding=pad)
+    (yd * wgt.double()).sum().backward()
+    torch.testing.assert_close(y.double(), yd.detach(), rtol=1e-4, atol=1e-5 * yd.abs().max().item())
+    gmax = xd.grad.abs().max().item()
+    print("stride-2 dx: max err / max", ((x.grad.double() - xd.grad).abs().max() / gmax).item())
+    torch.testing.assert_close(x.grad.double(), xd.grad, rtol=1e-3, atol=5e-5 * gmax)
