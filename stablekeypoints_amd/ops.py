@@ -855,7 +855,11 @@ def conv3x3_gn_fold_ok(x, norm: torch.nn.GroupNorm, weight) -> bool:
     if weight.requires_grad or not conv3x3_f4_ok(x.shape, weight.shape) or not group_norm_supported(x, norm.num_groups):
         return False
     B, ci, H, W = x.shape
-    return bool(N.lib().skp_conv3x3_f4_gn_ok(B, ci, int(weight.shape[0]), H, W))
+    co = int(weight.shape[0])
+    chunk = max(1, (2 ** 31 - 1) // (max(ci, co) * H * W * 4))            # the launch shape the batch chunks will have
+    rows = min(B, chunk)
+    return bool(N.lib().skp_conv3x3_f4_gn_ok(rows, ci, co, H, W)) and (B % rows == 0 or bool(
+        N.lib().skp_conv3x3_f4_gn_ok(B % rows, ci, co, H, W)))
 
 
 @torch.no_grad()
@@ -889,10 +893,13 @@ def conv3x3_gn_silu(x, norm: torch.nn.GroupNorm, weight, off=None, bias=None, re
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
     nblk = conv3x3_stats_blocks(x.shape, weight.shape) if want_stats else 0
     stats = torch.empty(B, cout, nblk, 2, device=x.device, dtype=torch.float32) if nblk else None
-    N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                      residual.data_ptr() if residual is not None else None, y.data_ptr(),
-                                      stats.data_ptr() if stats is not None else None, coef.data_ptr(), B, C, cout, H, W, st),
-            "skp_conv3x3_f4_gn_f32")
+    chunk = max(1, (2 ** 31 - 1) // (max(C, cout) * H * W * 4))          # rows per launch under the kernels' 2 GiB addressing limit
+    for b0 in range(0, B, chunk):
+        b1 = min(B, b0 + chunk)
+        N.check(lib.skp_conv3x3_f4_gn_f32(x[b0:b1].data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          residual[b0:b1].data_ptr() if residual is not None else None, y[b0:b1].data_ptr(),
+                                          stats[b0:b1].data_ptr() if stats is not None else None, coef[b0:b1].data_ptr(),
+                                          b1 - b0, C, cout, H, W, st), "skp_conv3x3_f4_gn_f32")
     if stats is not None:
         y._skp_blocks = (stats, nblk, 256)
     return y
