@@ -26,6 +26,9 @@
 #include "skp_common.h"
 #include <stdlib.h>
 
+#ifndef SKP_MAP_VBATCH
+#define SKP_MAP_VBATCH 3
+#endif
 #define SKP_MAP_XCAP 64           // slots per column in the quad-layer index lists (a column is touched by <= 5k/4 + 4 slots, k = R/s <= 32)
 
 struct MapArgs {
@@ -87,20 +90,36 @@ __device__ __forceinline__ void skp_v_phase(const float* __restrict__ Sg, float*
                                             const int* __restrict__ tab_cy, const float* __restrict__ tab_wy,
                                             int s, int rc, int tid, int ldt) {
     constexpr int TS = NT + 4, Q = NT / 4;
-    const float inv_s = 1.0f / (float)s;
+    constexpr int VB = SKP_MAP_VBATCH;                         // items whose loads go out before the first is used: the phase is
+    const float inv_s = 1.0f / (float)s;                       // latency-bound (L2 round trips), not bandwidth-bound
     const int items = rc * Q;
-#pragma unroll 2
-    for (int it = tid; it < items; it += 256) {
-        const int r = it / Q, q4 = it - r * Q;               // r = row*s + c
-        const int row = (int)(((float)r + 0.5f) * inv_s);
-        const int c = r - row * s;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it0 = tid; it0 < items; it0 += VB * 256) {
+        f32x4 raw[VB][4];
+        float wv[VB][4];
+        int dst[VB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * ldt + q4 * 4);
-            acc += tab_wy[row * 4 + j] * v;
+        for (int u = 0; u < VB; ++u) {
+            const int it = it0 + u * 256;
+            const int itc = it < items ? it : tid;             // a thread without a u-th item re-reads its first (discarded)
+            const int r = itc / Q, q4 = itc - r * Q;           // r = row*s + c
+            const int row = (int)(((float)r + 0.5f) * inv_s);
+            const int c = r - row * s;
+            dst[u] = it < items ? r * TS + q4 * 4 : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                raw[u][j] = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + j] * s + c)) * ldt + q4 * 4);
+                wv[u][j] = tab_wy[row * 4 + j];
+            }
         }
-        *(f32x4*)(Vt + r * TS + q4 * 4) = acc;
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            if (dst[u] >= 0) {
+                f32x4 acc = wv[u][0] * raw[u][0];
+#pragma unroll
+                for (int j = 1; j < 4; ++j) acc += wv[u][j] * raw[u][j];
+                *(f32x4*)(Vt + dst[u]) = acc;
+            }
+        }
     }
 }
 

@@ -75,13 +75,30 @@ void skp_attn_map_fwd_wide_kernel(WideArgs a, float* __restrict__ M,
         for (int h = 0; h < H; ++h, ++lh) {
             const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * a.ldt;
             // ---- V phase (the previous head's H phase finished before its combine barrier) ----
-            for (int it = tid; it < nc * Q; it += nthreads) {
-                const int c = it / Q, q4 = it - c * Q;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            // all loads of a thread's items go out before the first is used (the phase is latency-, not bandwidth-bound)
+            constexpr int VB = 3;
+            for (int it0 = tid; it0 < nc * Q; it0 += VB * nthreads) {
+                f32x4 raw[VB][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v += wy[j] * *(const f32x4*)(Sg + (size_t)(cy[j] * s + clo + c) * a.ldt + q4 * 4);
-                *(f32x4*)(Vt + c * TS + q4 * 4) = v;
+                for (int u = 0; u < VB; ++u) {
+                    const int it = it0 + u * nthreads;
+                    const int itc = it < nc * Q ? it : tid;
+                    const int c = itc / Q, q4 = itc - c * Q;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        raw[u][j] = *(const f32x4*)(Sg + (size_t)(cy[j] * s + clo + c) * a.ldt + q4 * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < VB; ++u) {
+                    const int it = it0 + u * nthreads;
+                    if (it < nc * Q) {
+                        const int c = it / Q, q4 = it - c * Q;
+                        f32x4 v = wy[0] * raw[u][0];
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) v += wy[j] * raw[u][j];
+                        *(f32x4*)(Vt + c * TS + q4 * 4) = v;
+                    }
+                }
             }
             __syncthreads();
             // ---- H phase: 64 tokens of this lane ----
