@@ -75,7 +75,8 @@ struct Wino4Args {
     int B, Cin, Cout, H, W;
     int tilesX, tilesPerImg, nTiles;
     unsigned x_bytes, u_bytes, y_bytes;
-    int steps;              // 16-channel stages per workgroup
+    int steps;              // 16-channel stages per workgroup (the last K split may hold fewer: total_steps - z * steps)
+    int total_steps;        // Cin / 16
     int ntb, ncg, tb_per_xcd;   // tile blocks, channel groups, tile blocks per XCD band (0: unit-grouped order)
     int splits;                 // K splits
     size_t y_split_stride;
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     const int tile0 = tblock * 32;
     const int n0 = (cg * 4 + wave) * 16;
     const int HW = a.H * a.W;
-    const int nsteps = a.steps;
-    const int cin_begin = zsplit * nsteps * 16;
+    const int nsteps = min(a.steps, a.total_steps - zsplit * a.steps);
+    const int cin_begin = zsplit * a.steps * 16;
 
     // ---- transform role: the 6x6 patches of 2 consecutive channels of one tile ----
     const int tl = tid & 31, cp = tid >> 5;
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     const int tile0 = tblock * 16;
     const int n0 = (cg * 4 + wave) * 32;             // this wave's 32 output channels (two 16-row MFMA blocks)
     const int HW = a.H * a.W;
-    const int nsteps = a.steps;
-    const int cin_begin = zsplit * nsteps * 16;
+    const int nsteps = min(a.steps, a.total_steps - zsplit * a.steps);
+    const int cin_begin = zsplit * a.steps * 16;
 
     // ---- transform role: the 6x6 patch of one channel of one tile ----
     const int tl = tid & 15, tc = tid >> 4;          // tile in the block, channel in the stage
@@ -634,27 +635,51 @@ static bool wino4_use_c128(int Cout, int tiles) {
     return tiles >= 256 && (Cout % 128 == 0 || (Cout > 128 && Cout % 128 >= 64));
 }
 
+// Workgroup grid of a launch with S K-splits (the order is explained at w4_work) and the number of waves of workgroups it
+// makes on the 256 CUs (one workgroup per CU: LDS).  In the unit-grouped order an XCD's 32 CUs take ceil(units / 8) units.
+struct Wino4Grid { int ntb, ncg, tb_per_xcd; unsigned gx; int rounds; };
+static Wino4Grid wino4_grid(int Cout, int tiles, int S) {
+    Wino4Grid g;
+    const bool c128 = wino4_use_c128(Cout, tiles);
+    g.ntb = c128 ? (tiles + 15) / 16 : (tiles + 31) / 32;
+    g.ncg = c128 ? (Cout + 127) / 128 : (Cout + 63) / 64;
+    g.tb_per_xcd = g.ntb >= (c128 ? 64 : 32) ? (g.ntb + 7) / 8 : 0;
+    if (g.tb_per_xcd) {
+        g.gx = 8u * g.tb_per_xcd * g.ncg;
+        g.rounds = (int)((g.gx * (unsigned)S + 255) / 256);
+    } else {
+        const int upx = (g.ncg * S + 7) / 8;
+        g.gx = 8u * upx * g.ntb;
+        g.rounds = (upx * g.ntb + 31) / 32;
+    }
+    return g;
+}
+
+// K splits of a launch: S workgroups share the Cin / 16 stages of one (tile block, channel group) unit, ceil(stages / S) each
+// (the last one takes what is left), partial outputs summed by skp_wino4_reduce_kernel in split order.
 int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     if ((Cin % 16) || (Cout % 16) || (H % 4) || (W % 4)) return 0;
     const int tiles = B * (H / 4) * (W / 4);
     const bool c128 = wino4_use_c128(Cout, tiles);
-    const int wgs = c128 ? ((tiles + 15) / 16) * ((Cout + 127) / 128) : ((tiles + 31) / 32) * ((Cout + 63) / 64);
     const int nsteps = Cin / 16;
     const double out_bytes = (double)B * Cout * H * W * 4;
-    if (const char* e = getenv("SKP_WINO_SPLIT")) {              // experiments: force the K split where it divides the stages
+    if (const char* e = getenv("SKP_WINO_SPLIT")) {              // experiments: force the K split
         const int S = atoi(e);
-        if (S >= 1 && S <= 16 && nsteps % S == 0) return S;
+        if (S >= 1 && S <= 16 && (S - 1) * ((nsteps + S - 1) / S) < nsteps) return S;
     }
     int best = 1;
     double best_cost = 1e30;
     // measured stage times (us): the 128-channel form ~3.9, the 64-channel form ~5.6 (tools/conv_bench.py with SKP_WINO_SPLIT
     // forced); the reduce pass streams (S + 1) x the output at ~8 TB/s (the partials are L2 / MALL resident)
     const double stage_us = c128 ? 3.9 : 5.6;
+    static const bool ragged = [] { const char* e = getenv("SKP_WINO_RAGGED"); return !(e && e[0] == '0'); }();
     for (int S = 1; S <= 16; ++S) {
-        if (nsteps % S) continue;
-        const int rounds = (wgs * S + 255) / 256;
-        double cost = rounds * (nsteps / S + 2.0) * stage_us;  // ~2 stages of prologue + epilogue per workgroup
+        const int per = (nsteps + S - 1) / S;
+        if ((S - 1) * per >= nsteps) continue;                   // an empty last split
+        if (!ragged && nsteps % S) continue;
+        const Wino4Grid g = wino4_grid(Cout, tiles, S);
+        double cost = g.rounds * (per + 2.0) * stage_us;       // ~2 stages of prologue + epilogue per workgroup
         if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
         if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
     }
@@ -736,7 +761,8 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     a.tilesPerImg = a.tilesX * (H / 4);
     a.nTiles = B * a.tilesPerImg;
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
-    a.steps = Cin / 16 / S;
+    a.total_steps = Cin / 16;
+    a.steps = (a.total_steps + S - 1) / S;
     a.splits = S;
     const size_t out_elems = (size_t)B * Cout * H * W;
     a.y_split_stride = out_elems;
@@ -765,11 +791,10 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
         attr_set = true;
     }
     const bool c128 = wino4_use_c128(Cout, a.nTiles);
+    const Wino4Grid g = wino4_grid(Cout, a.nTiles, S);
+    a.ntb = g.ntb; a.ncg = g.ncg; a.tb_per_xcd = g.tb_per_xcd;
+    const dim3 grid = g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1);
     if (c128) {                                     // 128 channels x 16 tiles per workgroup
-        a.ntb = (a.nTiles + 15) / 16;
-        a.ncg = (Cout + 127) / 128;
-        a.tb_per_xcd = a.ntb >= 64 ? (a.ntb + 7) / 8 : 0;
-        dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
         if (gncoef) {
             if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<true, true>), grid, dim3(256), lds_c, st, a);
             else hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<false, true>), grid, dim3(256), lds_c, st, a);
@@ -778,10 +803,6 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     } else if (gncoef) {
         return SKP_E_RANGE;
     } else {                                        // 64 channels x 32 tiles per workgroup
-        a.ntb = (a.nTiles + 31) / 32;
-        a.ncg = (Cout + 63) / 64;
-        a.tb_per_xcd = a.ntb >= 32 ? (a.ntb + 7) / 8 : 0;
-        dim3 grid = a.tb_per_xcd ? dim3(8 * a.tb_per_xcd * a.ncg, 1, S) : dim3(8 * ((a.ncg * S + 7) / 8) * a.ntb, 1, 1);
         if (a.stats) hipLaunchKernelGGL(skp_wino4_conv_kernel<true>, grid, dim3(256), lds, st, a);
         else hipLaunchKernelGGL(skp_wino4_conv_kernel<false>, grid, dim3(256), lds, st, a);
     }

@@ -529,3 +529,28 @@ def test_stride2_conv_input_gradient_own_kernels_vs_fp64(B, ci, co, H, W, pad):
     gmax = xd.grad.abs().max().item()
     print("stride-2 dx: max err / max", ((x.grad.double() - xd.grad).abs().max() / gmax).item())
     torch.testing.assert_close(x.grad.double(), xd.grad, rtol=1e-3, atol=5e-5 * gmax)
+
+
+@pytest.mark.parametrize("B,ci,co,H,S", [(2, 112, 64, 16, 2), (2, 112, 64, 16, 3), (2, 112, 96, 16, 4), (8, 208, 128, 32, 3),
+                                         (8, 176, 256, 32, 4), (1, 48, 64, 24, 2)])
+def test_winograd_f4_uneven_k_splits_vs_fp64(monkeypatch, B, ci, co, H, S):
+    """K splits that do not divide the 16-channel stages (the last workgroup of a unit takes the remainder): both workgroup
+    forms (64 channels x 32 tiles; 128 channels x 16 tiles at >= 256 tiles), partial sums reduced in split order -- against
+    fp64 conv2d, and twice for the same bits."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(B, ci, H, H, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, generator=g)
+    res = torch.randn(B, co, H, H, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    monkeypatch.setenv("SKP_WINO_SPLIT", str(S))
+    nbytes = ops.N.lib().skp_conv3x3_f4_workspace(B, ci, co, H, H)
+    assert nbytes == S * B * co * H * H * 4                 # the forced split is the plan
+    U = ops._wino4_filters(w.cuda(), False)
+    y = ops._conv3x3_f4_raw(x.cuda(), U, b.cuda(), co, residual=res.cuda())
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-4, atol=6e-5 * ref.abs().max().item())
+    assert torch.equal(ops._conv3x3_f4_raw(x.cuda(), U, b.cuda(), co, residual=res.cuda()), y)
+    monkeypatch.delenv("SKP_WINO_SPLIT")
+    y1 = ops._conv3x3_f4_raw(x.cuda(), U, b.cuda(), co, split=False, residual=res.cuda())
+    torch.testing.assert_close(y, y1, rtol=1e-4, atol=2e-5 * ref.abs().max().item())

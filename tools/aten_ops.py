@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--images", type=int, default=4)
     ap.add_argument("--skip", default="mm,addmm,bmm,baddbmm,linear,matmul", help="operators left out (library GEMMs)")
+    ap.add_argument("--gemm", action="store_true", help="list the library GEMMs instead (operator, shapes, calls, us, TF/s)")
     a = ap.parse_args()
     from stablekeypoints_amd import tuning
     from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
@@ -46,6 +47,8 @@ def main():
         step()
         torch.cuda.synchronize()
     skip = set(a.skip.split(","))
+    if a.gemm:
+        return gemm_table(prof, a.top)
     groups = {}
     for ev in prof.events():
         if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
@@ -68,6 +71,38 @@ def main():
     print(f"non-GEMM library device time in one step: {tot / 1e3:.2f} ms")
     for (name, shapes, frame), (t, n, kern) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:a.top]:
         print(f"{t / 1e3:7.3f} ms {n:4d}x  {name:<28} {shapes:<90} {frame}  [{kern[:50]}]")
+
+
+def gemm_table(prof, top):
+    """Library GEMM launches of the step grouped by (operator, operand shapes): calls, device us, fp32 TF/s."""
+    groups = {}
+    for ev in prof.events():
+        if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
+            continue
+        if ev.name.split("::")[-1] not in ("mm", "addmm", "bmm", "baddbmm"):
+            continue
+        t = sum(k.duration for k in ev.kernels)
+        shp = [s for s in ev.input_shapes if s]
+        mats = [s for s in shp if len(s) >= 2][-2:]
+        if len(mats) < 2:
+            continue
+        a_, b_ = mats
+        batch = a_[0] if len(a_) == 3 else 1
+        fl = 2.0 * batch * a_[-2] * a_[-1] * b_[-1]
+        frame = ""
+        for fr in (ev.stack or []):
+            if "stablekeypoints_amd" in fr:
+                frame = fr.split("stablekeypoints_amd/")[-1]
+                break
+        kern = ",".join(sorted({k.name[:44] for k in ev.kernels}))
+        key = (ev.name.split("::")[-1], str(a_), str(b_), frame[:48])
+        g = groups.setdefault(key, [0.0, 0, fl, kern])
+        g[0] += t; g[1] += 1
+    tot = sum(v[0] for v in groups.values())
+    print(f"library GEMM device time in one step: {tot / 1e3:.2f} ms in {sum(v[1] for v in groups.values())} launches")
+    for (name, sa, sb, frame), (t, n, fl, kern) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:top]:
+        tf = fl * n / (t * 1e-6) / 1e12
+        print(f"{t / 1e3:7.3f} ms {n:3d}x {t / n:7.1f} us {tf:6.1f} TF/s ({tf / 157.3:.2f}) {name:<6} {sa:<20} x {sb:<18} {frame:<48} [{kern}]")
 
 
 if __name__ == "__main__":

@@ -12,9 +12,13 @@ SHAPES = [  # name, B, Cin, Cout, H
     ("vae 128^2 512->512", 8, 512, 512, 128), ("vae 64^2 512->512", 8, 512, 512, 64),
     ("unet 64^2 320->320", 8, 320, 320, 64), ("unet 64^2 640->320", 8, 640, 320, 64), ("unet 64^2 960->320", 8, 960, 320, 64), ("unet 32^2 320->640", 8, 320, 640, 32),
     ("unet 32^2 640->640", 8, 640, 640, 32), ("unet 16^2 640->1280", 8, 640, 1280, 16),
-    ("unet 16^2 1280->1280", 8, 1280, 1280, 16), ("unet 8^2 1280->1280", 8, 1280, 1280, 8),
+    ("unet 16^2 1280->1280", 8, 1280, 1280, 16), ("unet 8^2 1280->1280", 8, 1280, 1280, 8), ("unet 8^2 2560->1280", 8, 2560, 1280, 8),
     ("unet 16^2 2560->1280", 8, 2560, 1280, 16), ("unet 32^2 1920->640", 8, 1920, 640, 32),
     ("unet 32^2 1280->640", 8, 1280, 640, 32), ("unet 32^2 960->640", 8, 960, 640, 32),
+    # backward-data launches (channel counts swapped)
+    ("bwd 16^2 1280->2560", 8, 1280, 2560, 16), ("bwd 8^2 1280->2560", 8, 1280, 2560, 8), ("bwd 32^2 640->1920", 8, 640, 1920, 32),
+    ("bwd 16^2 1280->1920", 8, 1280, 1920, 16), ("bwd 32^2 640->1280", 8, 640, 1280, 32), ("bwd 16^2 1280->640", 8, 1280, 640, 16),
+    ("bwd 32^2 640->960", 8, 640, 960, 32), ("bwd 64^2 320->640", 8, 320, 640, 64), ("bwd 64^2 320->960", 8, 320, 960, 64),
 ]
 
 
@@ -32,11 +36,21 @@ def timeit(fn, iters=10):
 def main():
     variants = [int(v) for v in sys.argv[1:]] or [0]
     torch.manual_seed(0)
+    only = os.environ.get("SKP_BENCH_ONLY", "")              # substring filter on the shape names
     for name, B, ci, co, H in SHAPES:
+        if only and not any(o in name for o in only.split(",")):
+            continue
         x = torch.randn(B, ci, H, H, device="cuda")
         w = torch.randn(co, ci, 3, 3, device="cuda") / (3 * ci ** 0.5)
         b = torch.randn(co, device="cuda")
         ref = F.conv2d(x, w, b, padding=1)
+        if os.environ.get("SKP_BENCH_F4_ONLY"):                    # the F(4x4) launch alone (K-split plan A/Bs)
+            U4 = ops._wino4_filters(w, False)
+            t4 = timeit(lambda: ops._conv3x3_f4_raw(x, U4, b, co), 30)
+            err4 = ((ops._conv3x3_f4_raw(x, U4, b, co) - ref).abs().max() / ref.abs().max()).item()
+            ws = ops.N.lib().skp_conv3x3_f4_workspace(B, ci, co, H, H)
+            print(f"{name:24s} F4 {t4 * 1e3:7.1f} us splits {ws // (B * co * H * H * 4) if ws else 1:2d} err {err4:.1e}", flush=True)
+            continue
         U = ops._wino_filters(w, False)
         fl = 2 * 9 * ci * co * B * H * H / 1e9
         t_lib = timeit(lambda: F.conv2d(x, w, b, padding=1))
