@@ -8,7 +8,8 @@
 // 512 registers of its SIMD: one wave per SIMD), so that the 6x6 -> 4x4 output transform stays in-lane:
 //   * skp_wino4_conv_kernel:      wave = 16 output channels x 32 tiles x 36 positions, workgroup = 64 channels x 32 tiles
 //   * skp_wino4_conv_c128_kernel: wave = 32 output channels x 16 tiles x 36 positions, workgroup = 128 channels x 16 tiles
-//     (Cout % 128 == 0 and >= 256 tiles): half the input-transform work per MFMA, two filter loads per position.
+//     (>= 128 tiles, Cout a multiple of 128 or its last group >= 64): half the input-transform work per MFMA, two filter
+//     loads per position.
 // The workgroup transforms the input patches of a 16-channel stage into LDS once (double buffered, 2 x 72 / 36 KB) in
 // MFMA operand order.  The transformed filter is streamed from L2 through a register ring (12 / 6 positions deep; VMEM
 // returns in order: everything queued behind a patch load inherits its latency, so the ring has to cover it).  The
@@ -626,13 +627,15 @@ __global__ void skp_wino4_reduce_kernel(const float* __restrict__ part, const fl
     ((f32x4*)y)[i] = acc;
 }
 
-// 128-channel workgroup form where there are enough tiles (measured: 12-16 % faster on the VAE / 32^2 UNet layers, slower at
-// 16^2 and below where the doubled filter traffic per tile dominates).  A ragged last channel group is fine (clamped filter
+// 128-channel workgroup form where there are enough tiles (measured: 12-16 % faster on the VAE / 32^2 UNet layers; at 16^2
+// (128 tiles at 8 rows) 5-18 % faster once the K splits fill the CUs evenly, at 8^2 no better than the 64-channel form:
+// profiles/r03_conv_splits.md).  A ragged last channel group is fine (clamped filter
 // rows, guarded stores): the 320-channel UNet layers run 3 groups (17 % idle MFMA rows) and still gain from the form's
 // shorter stages (one patch per thread instead of two).
 static bool wino4_use_c128(int Cout, int tiles) {
     if (const char* e = getenv("SKP_WINO_C128")) { if (e[0] == '0') return (Cout % 128 == 0) && tiles >= 256; }
-    return tiles >= 256 && (Cout % 128 == 0 || (Cout > 128 && Cout % 128 >= 64));
+    static const int min_tiles = [] { const char* e = getenv("SKP_WINO_C128_MIN_TILES"); return e ? atoi(e) : 128; }();
+    return tiles >= min_tiles && (Cout % 128 == 0 || (Cout > 128 && Cout % 128 >= 64));
 }
 
 // Workgroup grid of a launch with S K-splits (the order is explained at w4_work) and the number of waves of workgroups it
