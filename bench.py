@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--emulated-f32", action="store_true",
                     help="EXPERIMENT (separate line, never the bench of record): frozen nn.Linear GEMMs on the bf16 matrix "
                          "cores with three-term operand splits (csrc/skp_gemm_x3.hip)")
+    ap.add_argument("--cache-latents", action="store_true",
+                    help="EXPERIMENT (separate line, never the bench of record): latents of the un-warped views kept per dataset image "
+                         "(optimize.py cache_latents); the 16-image synthetic set then skips half the VAE work on every timed step")
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
                     help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/traffic_probe.py on "
@@ -449,18 +452,19 @@ def main():
     transform = RandomAffineWithInverse(args.augment_degrees, args.augment_scale, args.augment_translate)
 
     cursor = 0
+    latent_cache = {} if a.cache_latents else None
 
     def one_step():
         nonlocal cursor
         idx = [(cursor + i) % len(data) for i in range(per_rank)]
         cursor += per_rank
         images = torch.stack([data[i]["img"] for i in idx])
-        out = group_step(ldm, images, ctx, args, controller, transform, denom=global_batch)
+        out = group_step(ldm, images, ctx, args, controller, transform, denom=global_batch, latent_cache=latent_cache, ids=idx)
         reducer.step()
         return out
 
     one_step()                       # untimed pre-warm: MIOpen/hipBLASLt first-call solver selection, allocator growth
-    for _ in range(a.warmup):
+    for _ in range(a.warmup + (len(data) // per_rank if a.cache_latents else 0)):     # experiment: first epoch fills the cache
         one_step()
     D.barrier()
     torch.cuda.synchronize()
@@ -524,6 +528,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32-emulated (bf16x3 nn.Linear GEMMs, everything else f32)" if a.emulated_f32 else "f32",
             "data": "synthetic",
+            **({"experiment": "cache_latents: the un-warped views' latents are reused from the first epoch over the "
+                              f"{len(data)}-image synthetic set (half of each step's VAE work skipped); NOT the bench of record"}
+               if a.cache_latents else {}),
             "config": {"workload": f"{cfg_name}: {a.model} architecture UNet+VAE (seeded synthetic weights), "
                                    f"{image_size}x{image_size}, batch {per_rank} images/rank/step x 2 views, "
                                    f"T={a.tokens} tokens x {width}, R={a.res}, top_k={a.top_k} of {a.candidates}, fp32 end to end",

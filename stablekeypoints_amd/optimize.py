@@ -156,9 +156,22 @@ def _group_losses(controller, thetas, args, n):
     return tot_e, tot_s
 
 
-def group_step(ldm, images, context, args, controller, transform, denom, noise=None, thetas=None):
+def _latents_with_cache(ldm, images, warped, cache, ids, dev):
+    """Latents of [images; warped] with the un-warped views' rows taken from / added to `cache` (dataset index ->
+    [4,h,w]): `image2latent` is the posterior MEAN (ptp_utils.py:289-304), a pure function of the dataset image, so
+    from the second epoch on only the warped views go through the VAE encoder."""
+    miss = [j for j, i in enumerate(ids) if i not in cache]
+    enc = ptp_utils.image2latent(ldm, torch.cat([images[miss], warped], dim=0) if miss else warped, dev)
+    for r, j in enumerate(miss):
+        cache[ids[j]] = enc[r].clone()
+    return torch.cat([torch.stack([cache[i] for i in ids]), enc[len(miss):]], dim=0)
+
+
+def group_step(ldm, images, context, args, controller, transform, denom, noise=None, thetas=None, latent_cache=None,
+               ids=None):
     """Forward both views of `images` [n,3,H,W] as one batch, losses per image, backward of
-    sum_i (w_e*equiv_i + w_s*sharp_i)/denom into `context.grad`.  Returns detached (total, equiv, sharp)."""
+    sum_i (w_e*equiv_i + w_s*sharp_i)/denom into `context.grad`.  Returns detached (total, equiv, sharp).
+    `latent_cache` (dict) + `ids` (the dataset indices of `images`): opt-in reuse of the un-warped views' latents."""
     n = images.shape[0]
     dev = context.device
     images = images.to(dev)
@@ -166,9 +179,14 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
     thetas = transform.last_theta_host                           # host copy: no device read-back
     if thetas is None:
         thetas = transform.last_params["theta"].detach().cpu()   # caller passed device thetas
-    both = torch.cat([images, warped], dim=0)
-    ptp_utils.find_pred_noise(ldm, both, context, noise_level=args.noise_level, device=dev, noise=noise,
-                              early_exit=True, controllers={dev: controller})
+    if latent_cache is not None and ids is not None:
+        ptp_utils.find_pred_noise(ldm, None, context, noise_level=args.noise_level, device=dev, noise=noise, early_exit=True,
+                                  controllers={dev: controller},
+                                  latents=_latents_with_cache(ldm, images, warped, latent_cache, list(ids), dev))
+    else:
+        both = torch.cat([images, warped], dim=0)
+        ptp_utils.find_pred_noise(ldm, both, context, noise_level=args.noise_level, device=dev, noise=noise,
+                                  early_exit=True, controllers={dev: controller})
     tot_e, tot_s = _group_losses(controller, thetas, args, n)
     loss = (tot_e * args.equivariance_attn_loss_weight + tot_s * args.sharpening_loss_weight) / denom
     loss.backward()
@@ -204,6 +222,10 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
     shuffle_gen = torch.Generator(device="cpu").manual_seed(getattr(args, "seed", 0) + 1234)
     order, cursor = [], 0
     log_every = getattr(args, "log_interval", 50)
+    # opt-in (off: the reference encodes both views every step): latents of the un-warped views kept per dataset index,
+    # at most cache_latents_max entries (64 KB each at 512^2)
+    latent_cache = {} if getattr(args, "cache_latents", False) else None
+    cache_max = int(getattr(args, "cache_latents_max", 200_000))
     start = it_start = time.time()
     for step in range(int(args.num_steps)):
         running = torch.zeros(3, device=dev)
@@ -224,8 +246,10 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
                         raise ValueError("dataset smaller than the data-parallel width")
                 idx.append(order[cursor]); cursor += 1
             images = torch.stack([dataset[i]["img"] for i in idx])
+            if latent_cache is not None and len(latent_cache) + n > cache_max:
+                latent_cache.clear()
             running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size,
-                                              **inject))
+                                              latent_cache=latent_cache, ids=idx, **inject))
             done += n
         reducer.step()
         if trajectory_out is not None:
@@ -250,6 +274,7 @@ def default_args(**over):
              furthest_point_num_samples=25, top_k=10, num_subjects=1, sharpening_loss_weight=100,
              equivariance_attn_loss_weight=1000, layers=[0, 1, 2, 3], noise_level=-1, sigma=2.0,
              augment_degrees=15, augment_scale=[0.8, 1.0], augment_translate=[0.25, 0.25], wandb=False,
-             model_type="sd-legacy/stable-diffusion-v1-5", seed=0, image_size=512, log_interval=50)
+             model_type="sd-legacy/stable-diffusion-v1-5", seed=0, image_size=512, log_interval=50,
+             cache_latents=False, cache_latents_max=200_000)
     a.update(over)
     return SimpleNamespace(**a)

@@ -208,13 +208,17 @@ def image2latent(model, image, device):
 
 
 def find_pred_noise(ldm, image, context, noise_level=-1, device="cuda", noise=None, early_exit=False,
-                    controllers=None):
+                    controllers=None, latents=None):
     """ptp_utils.py:205-231.  `noise` lets a caller inject the gaussian (the reference draws it from the
     device RNG, :219).  `early_exit` stops the UNet after the last stored map -- result-identical for
-    `run_and_find_attn`, which discards the prediction (ptp_utils.py:246)."""
-    if isinstance(image, torch.Tensor) and image.dim() == 3:
-        image = image[None]
-    latent = image2latent(ldm, image, device)
+    `run_and_find_attn`, which discards the prediction (ptp_utils.py:246).  `latents` [B,4,h,w]: already encoded
+    rows (image2latent's output, e.g. kept from an earlier epoch) -- `image` is then ignored."""
+    if latents is not None:
+        latent = latents.to(device=device, dtype=torch.float32)
+    else:
+        if isinstance(image, torch.Tensor) and image.dim() == 3:
+            image = image[None]
+        latent = image2latent(ldm, image, device)
     if noise is None:
         noise = torch.randn_like(latent)
     t = ldm.scheduler.timesteps[noise_level]
