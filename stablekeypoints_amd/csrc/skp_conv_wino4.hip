@@ -19,6 +19,7 @@
 // Zero padding, ragged tile blocks, idle channel rows, bias and residual all go through raw buffer loads / stores whose
 // out-of-range offsets return 0 / are dropped: no divergent branch anywhere near the accumulators (a branch around
 // them costs hundreds of spilled registers).  fp32 throughout; relative error ~1e-5 of the output maximum.
+#include <algorithm>
 #include <type_traits>
 #include "skp_common.h"
 #include <stdlib.h>
@@ -80,6 +81,7 @@ struct Wino4Args {
     int total_steps;        // Cin / 16
     int ntb, ncg, tb_per_xcd;   // tile blocks, channel groups, tile blocks per XCD band (0: unit-grouped order)
     int splits;                 // K splits
+    int gx, vtotal;             // workgroup ids of one K split (band order) and in total: the persistent form walks id, id + grid, ...
     size_t y_split_stride;
     float* stats;               // optional [B][Cout][tilesPerImg/16][2] = {mean, sum (y - mean)^2} per 16-tile block (next GroupNorm), or null
     int sblk;                   // 16-tile blocks per image
@@ -120,16 +122,17 @@ __device__ __forceinline__ void w4_store_stats(const Wino4Args& a, const f32x2* 
 //    channel group fastest -> input tiles (all channel groups of a block, vertical halos of neighbours) are shared;
 //  * few tile blocks (small-spatial UNet layers, operand-traffic bound): all tile blocks of one (split, channel group)
 //    unit go to the same XCD, unit u -> XCD u % 8, so the unit's filter slice is fetched into that L2 once.
-__device__ __forceinline__ bool w4_work(const Wino4Args& a, int& tblock, int& cg, int& z) {
+__device__ __forceinline__ bool w4_work(const Wino4Args& a, int vid, int& tblock, int& cg, int& z) {
     if (a.tb_per_xcd > 0) {
-        const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+        z = vid / a.gx;
+        const int x = vid - z * a.gx;
+        const int xcd = x & 7, seq = x >> 3;
         const int tb_local = seq / a.ncg;
         cg = seq - tb_local * a.ncg;
         tblock = xcd * a.tb_per_xcd + tb_local;
-        z = blockIdx.z;
         return tblock < a.ntb;                                   // ragged band (whole workgroup)
     }
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int xcd = vid & 7, q = vid >> 3;
     const int ul = q / a.ntb;
     tblock = q - ul * a.ntb;
     const int u = ul * 8 + xcd;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     int tblock, cg, zsplit;
-    if (!w4_work(a, tblock, cg, zsplit)) return;
+    if (!w4_work(a, blockIdx.x + blockIdx.z * gridDim.x, tblock, cg, zsplit)) return;
     const int tile0 = tblock * 32;
     const int n0 = (cg * 4 + wave) * 16;
     const int HW = a.H * a.W;
@@ -386,51 +389,51 @@ constexpr int W4C_RING = 6;                      // ring slots per channel block
 // GNF: the input is x, not silu(GroupNorm(x)): every patch value goes through v = x * scale[b,c] + shift[b,c], v / (1 + e^-v)
 // on its way into the input transform (one pass over the activation saved per norm: the GroupNorm apply kernel disappears).
 // Zero padding stays zero: out-of-image rows / columns use (scale, shift) = (0, 0) and silu(0) = 0.
+// Persistent: a workgroup walks the work ids  blockIdx.x, + gridDim.x, ...  (w4_work's order, so the co-resident workgroups of
+// an XCD stay on one band).  While the LAST stage of a unit runs, its side jobs load and transform the first patches of the
+// NEXT unit (the transform role is retargeted before that stage), so per unit only the epilogue and the filter ring refill
+// are left outside the MFMA loop -- with 8 stages per unit (128 input channels) the prologue + dispatch gap was ~25 % of it.
 template <bool STATS, bool GNF = false>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a) {
-    extern __shared__ f32x4 vst[];                   // [2][36][4][16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ f32x4 vst[];                   // [2][36][4][16] stage buffers, then [32][64] float2 statistics slots
+    f32x2* const sst = (f32x2*)(vst + 2 * W4C_STAGE_F4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    int tblock, cg, zsplit;
-    if (!w4_work(a, tblock, cg, zsplit)) return;
-    const int tile0 = tblock * 16;
-    const int n0 = (cg * 4 + wave) * 32;             // this wave's 32 output channels (two 16-row MFMA blocks)
     const int HW = a.H * a.W;
-    const int nsteps = min(a.steps, a.total_steps - zsplit * a.steps);
-    const int cin_begin = zsplit * a.steps * 16;
+    int tblock, cg, zsplit;
+    int wid = blockIdx.x;
+    while (wid < a.vtotal && !w4_work(a, wid, tblock, cg, zsplit)) wid += gridDim.x;
+    if (wid >= a.vtotal) return;
 
     // ---- transform role: the 6x6 patch of one channel of one tile ----
     const int tl = tid & 15, tc = tid >> 4;          // tile in the block, channel in the stage
     int roff[6];
     bool lok, rok;
-    {
-        const int tg = tile0 + tl;
-        const bool tv = tg < a.nTiles;
+    int coff = SKP_OOB;                              // GNF: per-(image, channel) coefficients of the stage's channel `tc`
+    unsigned rowmask = 0;
+    auto aim_transform = [&](int tb, bool valid) {   // point the transform role at tile block tb (nothing: every load returns 0)
+        const int tg = tb * 16 + tl;
+        const bool tv = valid && tg < a.nTiles;
         const int tgc = tv ? tg : 0;
         const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
         const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
         const int base = (b * a.Cin + tc) * HW + 4 * tx;
+        rowmask = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int r = 4 * ty - 1 + i;
             roff[i] = (tv && r >= 0 && r < a.H) ? (base + r * a.W) * 4 : SKP_OOB;
+            rowmask |= (roff[i] != SKP_OOB ? 1u : 0u) << i;
         }
         lok = tx > 0;
         rok = tx + 1 < a.tilesX;
-    }
+        coff = valid ? (b * a.Cin + tc) * 8 : SKP_OOB;
+    };
+    aim_transform(tblock, true);
+    int cin_ld = zsplit * a.steps * 16;              // first input channel of the unit whose patches are being loaded
     const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
     const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
-    // GNF: per-(image, channel) coefficients of the stage's channel `tc`, fetched with the patch rows
     const i32x4 crs = skp_make_rsrc(a.gncoef, GNF ? (unsigned)a.B * a.Cin * 8u : 0u);
-    int coff = SKP_OOB;
-    unsigned rowmask = 0;
-    if (GNF) {
-        const int tg = tile0 + tl;
-        const int bq = (tg < a.nTiles ? tg : 0) / a.tilesPerImg;
-        coff = (bq * a.Cin + tc) * 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rowmask |= (roff[i] != SKP_OOB ? 1u : 0u) << i;
-    }
     f32x2 gcoef = {0.f, 0.f};
     f32x2 d[6][3];                                   // [row][column pair]: (c0,c5), (c1,c2), (c3,c4)
     auto gn_fetch = [&](int cin0) { if (GNF) gcoef = skp_buf_load_f32x2(crs, coff, cin0 * 8, 0); };
@@ -470,144 +473,162 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         for (int j = 0; j < 6; ++j) dst[j * (4 * 16 * 4)] = t[j];
     };
 
-    f32x4 acc[36][2];                                // [position][channel block]
+    // first unit: its first patches the plain way
+    gn_fetch(cin_ld);
 #pragma unroll
-    for (int p = 0; p < 36; ++p)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc[p][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int C16 = a.Cin >> 4;
-    int uvo[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) uvo[cb] = (kq * a.Cout + min(n0 + cb * 16 + i16, a.Cout - 1)) * 16;
-    const int u_c16 = 4 * a.Cout * 16, u_p = C16 * u_c16;
-
-    // ---- output role (lane = tile of the block, registers = 4 output channels per channel block) ----
-    int o_base;
-    bool t_ok;
-    {
-        const int tg = tile0 + i16;
-        t_ok = tg < a.nTiles;
-        const int tgc = t_ok ? tg : 0;
-        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
-        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
-        o_base = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
-    }
-
-    gn_fetch(cin_begin);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) load_row(cin_begin, i);
+    for (int i = 0; i < 6; ++i) load_row(cin_ld, i);
 #pragma unroll
     for (int i = 0; i < 6; ++i) gn_row(i);
 #pragma unroll
     for (int k = 0; k < 3; ++k) col_pass(k);
 #pragma unroll
     for (int i = 0; i < 6; ++i) row_pass_store(0, i);
-    f32x4 ua[W4C_RING][2];
-#pragma unroll
-    for (int q = 0; q < W4C_RING - 1; ++q)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) ua[q][cb] = skp_buf_load_f32x4(urs, uvo[cb], (cin_begin >> 4) * u_c16 + q * u_p, 0);
-    __syncthreads();
+    int bpar = 0;                                    // stage s of the current unit lives in buffer (bpar + s) & 1
 
-    auto run_stage = [&](int s, auto mode_c) {
-        constexpr int MODE = decltype(mode_c)::value;
-        const f32x4* vb = vst + (s & 1) * W4C_STAGE_F4 + kq * 16 + i16;
-        const int ub = ((cin_begin >> 4) + s) * u_c16;
-        f32x4 va[3];
-        va[0] = vb[0];
-        va[1] = vb[64];
-#pragma unroll
-        for (int p = 0; p < 36; ++p) {
-            {
-                constexpr int D = W4C_RING - 1;
-                const int q = p + D;
-                if (MODE == 0 || q < 36) {
-                    const int uo = q < 36 ? ub + q * u_p : ub + u_c16 + (q - 36) * u_p;
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) ua[q % W4C_RING][cb] = skp_buf_load_f32x4(urs, uvo[cb], uo, 0);
-                }
-            }
-            if (MODE == 0) {
-                if (p == 0) gn_fetch(cin_begin + (s + 1) * 16);
-                if (p < 6) load_row(cin_begin + (s + 1) * 16, p);
-                else if (GNF && p >= 21 && p < 27) gn_row(p - 21);
-                else if (p >= 27 && p < 30) col_pass(p - 27);
-                else if (p >= 30) row_pass_store((s + 1) & 1, p - 30);
-            }
-            if (p + 2 < 36) va[(p + 2) % 3] = vb[(p + 2) * 64];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-                    acc[p][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4C_RING][cb][m], va[p % 3][m], acc[p][cb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    for (int s = 0; s + 1 < nsteps; ++s) {
-        run_stage(s, std::integral_constant<int, 0>{});
-        __syncthreads();
-    }
-    run_stage(nsteps - 1, std::integral_constant<int, 1>{});
-    if (STATS) __syncthreads();                      // the epilogue parks statistics in the stage buffers
-
-    const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
+    const int C16 = a.Cin >> 4;
+    const int u_c16 = 4 * a.Cout * 16, u_p = C16 * u_c16;
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
     const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
-    f32x4 rr[8][4];                                  // [channel block * 4 + r][output row]
-    float bvs[8];
-    auto load_res = [&](int e) {
-        const int co = n0 + (e >> 2) * 16 + 4 * kq + (e & 3);
-        const bool ok = t_ok && co < a.Cout;
-        const int vo = (o_base + co * HW) * 4;
+
+    for (;;) {
+        const int tile0 = tblock * 16;
+        const int n0 = (cg * 4 + wave) * 32;         // this wave's 32 output channels (two 16-row MFMA blocks)
+        const int nsteps = min(a.steps, a.total_steps - zsplit * a.steps);
+        const int cin_begin = zsplit * a.steps * 16;
+        int uvo[2];
 #pragma unroll
-        for (int oy = 0; oy < 4; ++oy) rr[e][oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
-    };
+        for (int cb = 0; cb < 2; ++cb) uvo[cb] = (kq * a.Cout + min(n0 + cb * 16 + i16, a.Cout - 1)) * 16;
+        f32x4 ua[W4C_RING][2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int co = n0 + (e >> 2) * 16 + 4 * kq + (e & 3);
-        bvs[e] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
-    }
-    load_res(0);
-    load_res(1);
-    load_res(2);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < W4C_RING - 1; ++q)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int cb = e >> 2, r = e & 3;
-        const int co = n0 + cb * 16 + 4 * kq + r;
-        const bool ok = t_ok && co < a.Cout;
-        const int vo = (o_base + co * HW) * 4;
-        const float bv = bvs[e];
-        if (e + 3 < 8) load_res(e + 3);
-        float t[6][4];
+            for (int cb = 0; cb < 2; ++cb) ua[q][cb] = skp_buf_load_f32x4(urs, uvo[cb], (cin_begin >> 4) * u_c16 + q * u_p, 0);
+
+        // the unit after this one
+        int wnext = wid + gridDim.x, tb_n = 0, cg_n = 0, z_n = 0;
+        while (wnext < a.vtotal && !w4_work(a, wnext, tb_n, cg_n, z_n)) wnext += gridDim.x;
+        const bool has_next = wnext < a.vtotal;
+
+        f32x4 acc[36][2];                            // [position][channel block]
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            float m[6];
+        for (int p = 0; p < 36; ++p)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][cb][r];
-            w4_out1d(m, t[i]);
-        }
-#pragma unroll
-        for (int ox = 0; ox < 4; ++ox) {
-            float m[6], yv[4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
-            w4_out1d(m, yv);
-#pragma unroll
-            for (int oy = 0; oy < 4; ++oy) rr[e][oy][ox] += yv[oy] + bv;
-        }
-#pragma unroll
-        for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[e][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
-        if (STATS) w4_park_stats((f32x2*)vst, wave * 8 + e, lane, rr[e], ok);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (STATS) {                                     // 128 channels of one tile block
+            for (int cb = 0; cb < 2; ++cb) acc[p][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        if (tid < 128) {
-            const int wv = tid >> 5, lc = tid & 31;
-            w4_store_stats(a, (const f32x2*)vst, wv * 8 + ((lc >> 4) << 2) + (lc & 3), (lc >> 2) & 3, tile0, (cg * 4 + wv) * 32 + lc);
+
+        // MODE 0: a stage of the unit, loading / transforming the unit's next stage on the side; MODE 1: the unit's last stage,
+        // the side jobs work on the first stage of the NEXT unit (the transform role already points there; nothing -> zeros)
+        auto run_stage = [&](int s, auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            const f32x4* vb = vst + ((bpar + s) & 1) * W4C_STAGE_F4 + kq * 16 + i16;
+            const int ub = ((cin_begin >> 4) + s) * u_c16;
+            const int cin_side = MODE == 0 ? cin_ld + (s + 1) * 16 : cin_ld;
+            f32x4 va[3];
+            va[0] = vb[0];
+            va[1] = vb[64];
+#pragma unroll
+            for (int p = 0; p < 36; ++p) {
+                {
+                    constexpr int D = W4C_RING - 1;
+                    const int q = p + D;
+                    if (MODE == 0 || q < 36) {
+                        const int uo = q < 36 ? ub + q * u_p : ub + u_c16 + (q - 36) * u_p;
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) ua[q % W4C_RING][cb] = skp_buf_load_f32x4(urs, uvo[cb], uo, 0);
+                    }
+                }
+                if (p == 0) gn_fetch(cin_side);
+                if (p < 6) load_row(cin_side, p);
+                else if (GNF && p >= 21 && p < 27) gn_row(p - 21);
+                else if (p >= 27 && p < 30) col_pass(p - 27);
+                else if (p >= 30) row_pass_store((bpar + s + 1) & 1, p - 30);
+                if (p + 2 < 36) va[(p + 2) % 3] = vb[(p + 2) * 64];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[p][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4C_RING][cb][m], va[p % 3][m], acc[p][cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int s = 0; s + 1 < nsteps; ++s) {
+            run_stage(s, std::integral_constant<int, 0>{});
+            __syncthreads();
         }
+        aim_transform(tb_n, has_next);               // the unit's own patches are all loaded: retarget the transform role
+        cin_ld = z_n * a.steps * 16;
+        run_stage(nsteps - 1, std::integral_constant<int, 1>{});
+
+        // ---- epilogue: output role (lane = tile of the block, registers = 4 output channels per channel block) ----
+        int o_base;
+        bool t_ok;
+        {
+            const int tg = tile0 + i16;
+            t_ok = tg < a.nTiles;
+            const int tgc = t_ok ? tg : 0;
+            const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
+            const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+            o_base = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
+        }
+        const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
+        f32x4 rr[8][4];                              // [channel block * 4 + r][output row]
+        float bvs[8];
+        auto load_res = [&](int e) {
+            const int co = n0 + (e >> 2) * 16 + 4 * kq + (e & 3);
+            const bool ok = t_ok && co < a.Cout;
+            const int vo = (o_base + co * HW) * 4;
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) rr[e][oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+        };
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = n0 + (e >> 2) * 16 + 4 * kq + (e & 3);
+            bvs[e] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
+        }
+        constexpr int RD = GNF ? 2 : 3;              // residual rows in flight (the GNF forms carry more state across the epilogue)
+#pragma unroll
+        for (int e = 0; e < RD; ++e) load_res(e);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cb = e >> 2, r = e & 3;
+            const int co = n0 + cb * 16 + 4 * kq + r;
+            const bool ok = t_ok && co < a.Cout;
+            const int vo = (o_base + co * HW) * 4;
+            const float bv = bvs[e];
+            if (e + RD < 8) load_res(e + RD);
+            float t[6][4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float m[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][cb][r];
+                w4_out1d(m, t[i]);
+            }
+#pragma unroll
+            for (int ox = 0; ox < 4; ++ox) {
+                float m[6], yv[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
+                w4_out1d(m, yv);
+#pragma unroll
+                for (int oy = 0; oy < 4; ++oy) rr[e][oy][ox] += yv[oy] + bv;
+            }
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[e][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            if (STATS) w4_park_stats(sst, wave * 8 + e, lane, rr[e], ok);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (STATS) {                                 // 128 channels of one tile block
+            __syncthreads();
+            if (tid < 128) {
+                const int wv = tid >> 5, lc = tid & 31;
+                w4_store_stats(a, sst, wv * 8 + ((lc >> 4) << 2) + (lc & 3), (lc >> 2) & 3, tile0, (cg * 4 + wv) * 32 + lc);
+            }
+        }
+        if (!has_next) break;
+        bpar = (bpar + nsteps) & 1;
+        wid = wnext; tblock = tb_n; cg = cg_n; zsplit = z_n;
     }
 }
 
@@ -776,7 +797,7 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     a.sblk = a.tilesPerImg / 16;
     a.gncoef = gncoef;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4), lds_c = (size_t)2 * W4C_STAGE_F4 * sizeof(f32x4);
+    const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4), lds_c = (size_t)2 * W4C_STAGE_F4 * sizeof(f32x4) + 32 * 64 * sizeof(f32x2);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)skp_wino4_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -796,7 +817,12 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     const bool c128 = wino4_use_c128(Cout, a.nTiles);
     const Wino4Grid g = wino4_grid(Cout, a.nTiles, S);
     a.ntb = g.ntb; a.ncg = g.ncg; a.tb_per_xcd = g.tb_per_xcd;
-    const dim3 grid = g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1);
+    a.gx = (int)g.gx;
+    a.vtotal = g.tb_per_xcd ? (int)g.gx * S : (int)g.gx;
+    // 128-channel form: persistent workgroups, one per CU (the ids are multiples of 8 apart, so a workgroup stays on its XCD's band)
+    static const int persist = [] { const char* e = getenv("SKP_WINO_PERSIST"); return e ? atoi(e) : 256; }();
+    const dim3 grid = c128 ? dim3((unsigned)(persist > 0 ? std::min(a.vtotal, persist & ~7) : a.vtotal), 1, 1)
+                           : (g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1));
     if (c128) {                                     // 128 channels x 16 tiles per workgroup
         if (gncoef) {
             if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<true, true>), grid, dim3(256), lds_c, st, a);

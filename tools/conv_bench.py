@@ -15,6 +15,10 @@ SHAPES = [  # name, B, Cin, Cout, H
     ("unet 16^2 1280->1280", 8, 1280, 1280, 16), ("unet 8^2 1280->1280", 8, 1280, 1280, 8), ("unet 8^2 2560->1280", 8, 2560, 1280, 8),
     ("unet 16^2 2560->1280", 8, 2560, 1280, 16), ("unet 32^2 1920->640", 8, 1920, 640, 32),
     ("unet 32^2 1280->640", 8, 1280, 640, 32), ("unet 32^2 960->640", 8, 960, 640, 32),
+    # stage-time probes: same spatial size and output channels, growing Cin (SKP_BENCH_ONLY=probe)
+    ("probe 512^2 B4 128->128", 4, 128, 128, 512), ("probe 512^2 B4 256->128", 4, 256, 128, 512), ("probe 512^2 B4 384->128", 4, 384, 128, 512),
+    ("probe 256^2 B8 128->128", 8, 128, 128, 256), ("probe 256^2 B8 256->128", 8, 256, 128, 256), ("probe 256^2 B8 512->128", 8, 512, 128, 256),
+    ("probe 128^2 B8 128->512", 8, 128, 512, 128), ("probe 128^2 B8 256->512", 8, 256, 512, 128), ("probe 128^2 B8 512->512", 8, 512, 512, 128),
     # backward-data launches (channel counts swapped)
     ("bwd 16^2 1280->2560", 8, 1280, 2560, 16), ("bwd 8^2 1280->2560", 8, 1280, 2560, 8), ("bwd 32^2 640->1920", 8, 640, 1920, 32),
     ("bwd 16^2 1280->1920", 8, 1280, 1920, 16), ("bwd 32^2 640->1280", 8, 640, 1280, 32), ("bwd 16^2 1280->640", 8, 1280, 640, 16),
