@@ -195,8 +195,50 @@ def conv_roofline(ops, B, image_size, iters, device):
     t = e0.elapsed_time(e1) / iters * 1e-3
     direct = 2.0 * 9 * ci * co * B * image_size * image_size
     nbytes = 4 * (B * ci * image_size ** 2 + B * co * image_size ** 2 + 36 * ci * co)
-    grid_threads = 8 * ((((B * (image_size // 4) ** 2 + 15) // 16) + 7) // 8) * (co // 128) * 256   # 128-channel form
+    units = 8 * ((((B * (image_size // 4) ** 2 + 15) // 16) + 7) // 8) * (co // 128)
+    grid_threads = min(units, 256) * 256                         # 128-channel form: persistent, one workgroup per CU
     return t, direct, nbytes, grid_threads, B
+
+
+def conv_step_forms(ops, B, image_size, iters, device):
+    """The same kernel in the forms and at the launch shapes the step actually runs (micro-timed like conv_roofline): the
+    first-level VAE convolutions carry the GroupNorm + SiLU of their input in the patch load and leave block statistics
+    for the next GroupNorm behind; the deeper levels are the plain kernel with the statistics epilogue."""
+    lib, N = ops.N.lib(), ops.N
+    g = torch.Generator(device="cpu").manual_seed(3)
+    out = []
+    for (ci, co, sz, form) in ((128, 128, image_size, "gn_fold+stats"), (256, 256, image_size // 2, "stats"),
+                               (512, 512, image_size // 4, "stats"), (320, 320, image_size // 8, "stats")):
+        rows = min(B, max(1, (2 ** 31 - 1) // (max(ci, co) * sz * sz * 4)))
+        x = torch.randn(rows, ci, sz, sz, generator=g).to(device)
+        w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
+        U = ops._wino4_filters(w, False)
+        nblk = ops.conv3x3_stats_blocks(x.shape, w.shape)
+        if not nblk:
+            continue
+        stats = torch.empty(rows, co, nblk, 2, device=device)
+        y = torch.empty(rows, co, sz, sz, device=device)
+        if form.startswith("gn_fold"):
+            if not lib.skp_conv3x3_f4_gn_ok(rows, ci, co, sz, sz):
+                continue
+            coef = torch.stack([torch.full((rows, ci), 0.7), torch.full((rows, ci), 0.1)], dim=-1).to(device).contiguous()
+            fn = lambda: N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), None, None, y.data_ptr(), stats.data_ptr(),
+                                                           coef.data_ptr(), rows, ci, co, sz, sz, ops._stream()), "skp_conv3x3_f4_gn_f32")
+        else:
+            fn = lambda: ops._conv3x3_f4_raw(x, U, None, co, out=y, stats=stats)
+        for _ in range(6):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / iters * 1e-3
+        fl = 2.0 * 9 * ci * co * rows * sz * sz / 4
+        out.append({"shape": f"{ci}->{co} ch at {sz}^2, {rows} rows", "form": form, "launch_us": t * 1e6, "algorithmic_flops": fl,
+                    "achieved": fl / t / 1e12, "frac": fl / t / 1e12 / F32_MATRIX_PEAK_TF})
+        del x, y, stats, U, w
+    return out
 
 
 def cpu_baseline(ldm_cpu, args):
@@ -492,6 +534,7 @@ def main():
         kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev, ldims, a.top_k)
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(10, a.kernel_iters // 3), dev)
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
+        cv_forms = conv_step_forms(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
         issue1, issue2 = ops.mfma_issue_rate(1, device=dev), ops.mfma_issue_rate(2, device=dev)
@@ -539,13 +582,14 @@ def main():
             # dominant kernel of the step by time: the Winograd conv of the frozen blocks, priced on the
             # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
             "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {min(image_size, 512)}^2, "
-                                   f"{cv_rows} rows: heaviest launch shape of the step)",
+                                   f"{cv_rows} rows: heaviest launch shape of the step, plain form as in rounds 1-2; "
+                                   f"step_forms lists the forms / shapes the step launches)",
                          "bound": "mfma", "achieved": cv_direct / 4 / cv_t / 1e12, "peak": F32_MATRIX_PEAK_TF,
                          "unit": "TFLOP/s", "frac": cv_direct / 4 / cv_t / 1e12 / F32_MATRIX_PEAK_TF,
                          "traffic": conv_traffic, "traffic_source": conv_src,
                          "launch_us": cv_t * 1e6, "algorithmic_flops": cv_direct / 4, "algorithmic_bytes": cv_bytes,
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
-                         "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)"},
+                         "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "step_forms": cv_forms},
             # the north-star attention kernel (BASELINE metric: "fraction of the attention roofline")
             "roofline_attn_map": {"kernel": kt["fwd_kernel"] + " (fused up-res softmax map, forward)", "bwd_route": kt["bwd_route"],
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -53,7 +53,13 @@ def main():
             t4 = timeit(lambda: ops._conv3x3_f4_raw(x, U4, b, co), 30)
             err4 = ((ops._conv3x3_f4_raw(x, U4, b, co) - ref).abs().max() / ref.abs().max()).item()
             ws = ops.N.lib().skp_conv3x3_f4_workspace(B, ci, co, H, H)
-            print(f"{name:24s} F4 {t4 * 1e3:7.1f} us splits {ws // (B * co * H * H * 4) if ws else 1:2d} err {err4:.1e}", flush=True)
+            nblk = ops.conv3x3_stats_blocks(x.shape, w.shape)
+            ts = float("nan")
+            if nblk:                                              # the same launch with the block-statistics epilogue
+                st = torch.empty(B, co, nblk, 2, device="cuda")
+                ts = timeit(lambda: ops._conv3x3_f4_raw(x, U4, b, co, stats=st), 30)
+            print(f"{name:24s} F4 {t4 * 1e3:7.1f} us splits {ws // (B * co * H * H * 4) if ws else 1:2d} err {err4:.1e} | with statistics "
+                  f"{ts * 1e3:7.1f} us", flush=True)
             continue
         U = ops._wino_filters(w, False)
         fl = 2 * 9 * ci * co * B * H * H / 1e9

@@ -8,7 +8,7 @@ import sys
 CLASSES = [
     ("skp conv3x3 (Winograd stride 1 + direct stride 2)", ("skp_wino", "skp_conv_s2")),
     ("skp flash attention (self + long-key cross)", ("skp_self_attn", "skp_fa2_")),
-    ("skp attention map fwd/bwd (north-star kernel)", ("skp_attn_map",)),
+    ("skp attention map fwd/bwd (north-star kernel)", ("skp_attn_map", "skp_map_")),
     ("skp fused GroupNorm+SiLU / bias+residual", ("skp_group_norm", "skp_gn_", "skp_add_bias")),
     ("skp cross-attn (T<=128) / selection / loss / small gemm / geglu / layout", ("skp_",)),
     ("conv (MIOpen)", ("igemm", "Igemm", "conv", "Conv", "winograd", "Winograd", "gridwise_convolution", "naive_conv",
@@ -74,6 +74,20 @@ def main():
     print("| kernel | grid | calls/step | avg us | ms/step |\n|---|---|---|---|---|")
     for (n, grid), (ns, c) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:40]:
         print(f"| {n} | {grid} | {c / nwin:.1f} | {ns / c / 1e3:.1f} | {ns / nwin / 1e6:.2f} |")
+    # the 128-channel Winograd form is persistent (256 workgroups whatever the layer): its launches are told apart by their
+    # position in the step's launch order, which is the same every step
+    seqs = []
+    for k in range(nwin):
+        lo, hi = bounds[-1 - nwin + k], bounds[-nwin + k]
+        seqs.append([(name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:60], en - st)
+                     for st, en, name, _ in rows if st >= lo and en <= hi and "skp_wino4_conv_c128_kernel" in name])
+    if seqs and seqs[0] and all(len(q) == len(seqs[0]) for q in seqs):
+        print("\npersistent 128-channel Winograd launches in launch order (# = position among this kernel's launches of a step; "
+              "the VAE encoder comes first: #0-#3 are the 128 -> 128 convolutions at image resolution), 24 heaviest")
+        print("| # | kernel form <STATS, GNF> | avg us |\n|---|---|---|")
+        avg = [(i, seqs[0][i][0], sum(q[i][1] for q in seqs) / nwin / 1e3) for i in range(len(seqs[0]))]
+        for i, n, us in sorted(sorted(avg, key=lambda r: -r[2])[:24]):
+            print(f"| {i} | {n.replace('skp_wino4_conv_c128_kernel', '')} | {us:.1f} |")
 
 
 if __name__ == "__main__":
