@@ -632,267 +632,6 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     }
 }
 
-// ---- 8-wave form of the 128-channel x 16-tile workgroup: TWO waves per SIMD -------------------------------------------------
-// Same unit, LDS stage layout, filter layout and persistent walk as skp_wino4_conv_c128_kernel, but a wave owns 16 output
-// channels (36 accumulator tiles = 144 registers, of the 256 a wave may hold at two waves per SIMD): back-to-back fp32 MFMAs of
-// one wave leave issue gaps that a second wave fills (0.77 -> 0.86 of the nominal rate, profiles/r02_mfma_valu_probe.md).
-// The 256 patches of a stage are transformed by 512 threads: lanes 0-31 of a wave take patch columns 0..2, lanes 32-63 columns
-// 5,3,4 (scalar + float2 loads), each does the column pass on its three columns, the halves trade three rows each with
-// v_permlane32_swap (9 instructions, no selects: both halves end up with the same register roles), and each does the row pass
-// + LDS stores of three rows.
-constexpr int W8_RING = 6;
-template <bool STATS, bool GNF = false>
-__global__ __launch_bounds__(512) void skp_wino4_conv_w8_kernel(Wino4Args a) {
-    extern __shared__ f32x4 vst[];                   // [2][36][4][16] stage buffers, then [32][64] float2 statistics slots
-    f32x2* const sst = (f32x2*)(vst + 2 * W4C_STAGE_F4);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int HW = a.H * a.W;
-    int tblock, cg, zsplit;
-    int wid = blockIdx.x;
-    while (wid < a.vtotal && !w4_work(a, wid, tblock, cg, zsplit)) wid += gridDim.x;
-    if (wid >= a.vtotal) return;
-
-    // ---- transform role: half of the 6x6 patch of one channel of one tile ----
-    const int half = lane >> 5;
-    const int pid = wave * 32 + (lane & 31);
-    const int tl = pid & 15, tc = pid >> 4;          // tile in the block, channel in the stage
-    const int sdel = half ? 8 : -4;                  // the scalar column (5 | 0) relative to the float2 (columns 3,4 | 1,2)
-    int roff[6];                                     // byte offset of the float2 of row i, or SKP_OOB
-    bool sok;                                        // the scalar column lies inside the image
-    int coff = SKP_OOB;
-    unsigned rowmask = 0;
-    auto aim_transform = [&](int tb, bool valid) {
-        const int tg = tb * 16 + tl;
-        const bool tv = valid && tg < a.nTiles;
-        const int tgc = tv ? tg : 0;
-        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
-        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
-        const int base = (b * a.Cin + tc) * HW + 4 * tx + 2 * half;
-        rowmask = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int r = 4 * ty - 1 + i;
-            roff[i] = (tv && r >= 0 && r < a.H) ? (base + r * a.W) * 4 : SKP_OOB;
-            rowmask |= (roff[i] != SKP_OOB ? 1u : 0u) << i;
-        }
-        sok = half ? (tx + 1 < a.tilesX) : (tx > 0);
-        coff = valid ? (b * a.Cin + tc) * 8 : SKP_OOB;
-    };
-    aim_transform(tblock, true);
-    int cin_ld = zsplit * a.steps * 16;
-    const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
-    const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
-    const i32x4 crs = skp_make_rsrc(a.gncoef, GNF ? (unsigned)a.B * a.Cin * 8u : 0u);
-    f32x2 gcoef = {0.f, 0.f};
-    f32x2 dm[6];                                     // row i: columns (1,2) | (3,4)
-    float ds[6];                                     // row i: column 0 | 5
-    auto gn_fetch = [&](int cin0) { if (GNF) gcoef = skp_buf_load_f32x2(crs, coff, cin0 * 8, 0); };
-    auto gn_row = [&](int i) {
-        if (GNF) {
-            const bool rv = (rowmask >> i) & 1u;
-            const float sc = rv ? gcoef[0] : 0.f, sh = rv ? gcoef[1] : 0.f;
-            auto act = [](float x, float s, float h) { const float v = fmaf(x, s, h); return v / (1.0f + __expf(-v)); };
-            ds[i] = act(ds[i], sok ? sc : 0.f, sok ? sh : 0.f);
-            dm[i][0] = act(dm[i][0], sc, sh);
-            dm[i][1] = act(dm[i][1], sc, sh);
-        }
-    };
-    auto load_row = [&](int cin0, int i) {
-        const int so = cin0 * HW * 4;
-        dm[i] = skp_buf_load_f32x2(xrs, roff[i], so, 0);
-        ds[i] = skp_buf_load_f32(xrs, (sok && ((rowmask >> i) & 1u)) ? roff[i] + sdel : SKP_OOB, so, 0);
-    };
-    auto col_pass = [&](int k) {
-        if (k == 0) {
-            float v[6], t[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = ds[i];
-            w4_in1d(v, t);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ds[i] = t[i];
-        } else {
-            f32x2 v[6], t[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) v[i] = dm[i];
-            w4_in1d(v, t);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) dm[i] = t[i];
-        }
-    };
-    auto swap32 = [](float& x, float& y) {          // x of lanes 32-63 <-> y of lanes 0-31
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-        x = __uint_as_float(r[0]);
-        y = __uint_as_float(r[1]);
-    };
-    auto trade_rows = [&]() {                        // afterwards a lane holds all six columns of rows 3 * half + (0..2)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            swap32(ds[j], ds[3 + j]);
-            float x0 = dm[j][0], y0 = dm[3 + j][0], x1 = dm[j][1], y1 = dm[3 + j][1];
-            swap32(x0, y0);
-            swap32(x1, y1);
-            dm[j] = f32x2{x0, x1};
-            dm[3 + j] = f32x2{y0, y1};
-        }
-    };
-    auto row_pass_store = [&](int buf, int j) {      // row 3 * half + j
-        float r0[6] = {ds[j], dm[j][0], dm[j][1], dm[3 + j][0], dm[3 + j][1], ds[3 + j]};
-        float t[6];
-        w4_in1d(r0, t);
-        const int i = 3 * half + j;
-        float* dst = (float*)(vst + buf * W4C_STAGE_F4) + (((i * 6) * 4 + (tc >> 2)) * 16 + tl) * 4 + (tc & 3);
-#pragma unroll
-        for (int jj = 0; jj < 6; ++jj) dst[jj * (4 * 16 * 4)] = t[jj];
-    };
-
-    gn_fetch(cin_ld);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) load_row(cin_ld, i);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gn_row(i);
-    col_pass(0);
-    col_pass(1);
-    trade_rows();
-#pragma unroll
-    for (int j = 0; j < 3; ++j) row_pass_store(0, j);
-    int bpar = 0;
-
-    const int C16 = a.Cin >> 4;
-    const int u_c16 = 4 * a.Cout * 16, u_p = C16 * u_c16;
-    const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
-    const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
-
-    for (;;) {
-        const int tile0 = tblock * 16;
-        const int n0 = cg * 128 + wave * 16;         // this wave's 16 output channels
-        const int nsteps = min(a.steps, a.total_steps - zsplit * a.steps);
-        const int cin_begin = zsplit * a.steps * 16;
-        const int uvo = (kq * a.Cout + min(n0 + i16, a.Cout - 1)) * 16;
-        f32x4 ua[W8_RING];
-#pragma unroll
-        for (int q = 0; q < W8_RING - 1; ++q) ua[q] = skp_buf_load_f32x4(urs, uvo, (cin_begin >> 4) * u_c16 + q * u_p, 0);
-
-        int wnext = wid + gridDim.x, tb_n = 0, cg_n = 0, z_n = 0;
-        while (wnext < a.vtotal && !w4_work(a, wnext, tb_n, cg_n, z_n)) wnext += gridDim.x;
-        const bool has_next = wnext < a.vtotal;
-
-        f32x4 acc[36];
-#pragma unroll
-        for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-
-        auto run_stage = [&](int s, auto mode_c) {
-            constexpr int MODE = decltype(mode_c)::value;
-            const f32x4* vb = vst + ((bpar + s) & 1) * W4C_STAGE_F4 + kq * 16 + i16;
-            const int ub = ((cin_begin >> 4) + s) * u_c16;
-            const int cin_side = MODE == 0 ? cin_ld + (s + 1) * 16 : cin_ld;
-            f32x4 va[3];
-            va[0] = vb[0];
-            va[1] = vb[64];
-#pragma unroll
-            for (int p = 0; p < 36; ++p) {
-                {
-                    constexpr int D = W8_RING - 1;
-                    const int q = p + D;
-                    if (MODE == 0 || q < 36) {
-                        const int uo = q < 36 ? ub + q * u_p : ub + u_c16 + (q - 36) * u_p;
-                        ua[q % W8_RING] = skp_buf_load_f32x4(urs, uvo, uo, 0);
-                    }
-                }
-                if (p == 0) gn_fetch(cin_side);
-                if (p < 6) load_row(cin_side, p);
-                else if (GNF && p >= 18 && p < 24) gn_row(p - 18);
-                else if (p == 24) col_pass(0);
-                else if (p == 25) col_pass(1);
-                else if (p == 26) trade_rows();
-                else if (p == 28 || p == 30 || p == 32) row_pass_store((bpar + s + 1) & 1, (p - 28) >> 1);
-                if (p + 2 < 36) va[(p + 2) % 3] = vb[(p + 2) * 64];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W8_RING][m], va[p % 3][m], acc[p], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        for (int s = 0; s + 1 < nsteps; ++s) {
-            run_stage(s, std::integral_constant<int, 0>{});
-            __syncthreads();
-        }
-        aim_transform(tb_n, has_next);
-        cin_ld = z_n * a.steps * 16;
-        run_stage(nsteps - 1, std::integral_constant<int, 1>{});
-
-        // ---- epilogue: lane = tile of the block, registers = 4 output channels ----
-        int o_base;
-        bool t_ok;
-        {
-            const int tg = tile0 + i16;
-            t_ok = tg < a.nTiles;
-            const int tgc = t_ok ? tg : 0;
-            const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
-            const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
-            o_base = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
-        }
-        const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
-        f32x4 rr[4][4];                              // [r][output row]
-        float bvs[4];
-        auto load_res = [&](int e) {
-            const int co = n0 + 4 * kq + e;
-            const bool ok = t_ok && co < a.Cout;
-            const int vo = (o_base + co * HW) * 4;
-#pragma unroll
-            for (int oy = 0; oy < 4; ++oy) rr[e][oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
-        };
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = n0 + 4 * kq + e;
-            bvs[e] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
-        }
-        load_res(0);
-        load_res(1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = n0 + 4 * kq + e;
-            const bool ok = t_ok && co < a.Cout;
-            const int vo = (o_base + co * HW) * 4;
-            const float bv = bvs[e];
-            if (e + 2 < 4) load_res(e + 2);
-            float t[6][4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][e];
-                w4_out1d(m, t[i]);
-            }
-#pragma unroll
-            for (int ox = 0; ox < 4; ++ox) {
-                float m[6], yv[4];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
-                w4_out1d(m, yv);
-#pragma unroll
-                for (int oy = 0; oy < 4; ++oy) rr[e][oy][ox] += yv[oy] + bv;
-            }
-#pragma unroll
-            for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[e][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
-            if (STATS) w4_park_stats(sst, wave * 4 + e, lane, rr[e], ok);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (STATS) {                                 // 128 channels of one tile block
-            __syncthreads();
-            if (tid < 128) {
-                const int wv = tid >> 4, cc = tid & 15;
-                w4_store_stats(a, sst, wv * 4 + (cc & 3), cc >> 2, tile0, cg * 128 + tid);
-            }
-        }
-        if (!has_next) break;
-        bpar = (bpar + nsteps) & 1;
-        wid = wnext; tblock = tb_n; cg = cg_n; zsplit = z_n;
-    }
-}
-
 // y = sum_z part[z] (+ bias[channel]) (+ res), fixed order
 __global__ void skp_wino4_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                         const float* __restrict__ res, float* __restrict__ y, size_t n4, size_t stride,
@@ -1069,14 +808,6 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)skp_wino4_conv_w8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)skp_wino4_conv_w8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)skp_wino4_conv_w8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute((const void*)skp_wino4_conv_w8_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
-        if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)skp_wino4_conv_c128_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
@@ -1092,14 +823,7 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     static const int persist = [] { const char* e = getenv("SKP_WINO_PERSIST"); return e ? atoi(e) : 256; }();
     const dim3 grid = c128 ? dim3((unsigned)(persist > 0 ? std::min(a.vtotal, persist & ~7) : a.vtotal), 1, 1)
                            : (g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1));
-    static const bool w8 = [] { const char* e = getenv("SKP_WINO_W8"); return e && e[0] == '1'; }();
-    if (c128 && w8 && persist > 0) {                // 128 channels x 16 tiles per workgroup, eight waves (two per SIMD)
-        if (gncoef) {
-            if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_w8_kernel<true, true>), grid, dim3(512), lds_c, st, a);
-            else hipLaunchKernelGGL((skp_wino4_conv_w8_kernel<false, true>), grid, dim3(512), lds_c, st, a);
-        } else if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_w8_kernel<true, false>), grid, dim3(512), lds_c, st, a);
-        else hipLaunchKernelGGL((skp_wino4_conv_w8_kernel<false, false>), grid, dim3(512), lds_c, st, a);
-    } else if (c128) {                              // 128 channels x 16 tiles per workgroup
+    if (c128) {                                     // 128 channels x 16 tiles per workgroup
         if (gncoef) {
             if (a.stats) hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<true, true>), grid, dim3(256), lds_c, st, a);
             else hipLaunchKernelGGL((skp_wino4_conv_c128_kernel<false, true>), grid, dim3(256), lds_c, st, a);
