@@ -207,6 +207,19 @@ int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma,
 int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias, float* out, int N, int C, int HW,
                               void* stream);
 
+/* Residual add + LayerNorm of the transformer blocks (diffusers BasicTransformerBlock [third party]: `attn(norm(h)) + h`
+ * chains, reached from ptp_utils.py:213-217) in one pass per direction.  Rows of C floats, C a multiple of 32 with
+ * C / 32 .. C / 256 in {1..6, 8} float4 per lane (skp_add_layer_norm_ok(C) == 1: 320, 640, 1280, 1024, 768, 512, 64, 32 ...).
+ * fwd: x = d + h (d may be NULL: x is then not written and n = LN(h)), n = (x - mean) * rstd * gamma + beta,
+ *      stat [rows][2] = (mean, rstd); two-pass statistics.
+ * bwd: dx = LN'(dn; x, stat, gamma) (+ dskip, the gradient reaching x from its other uses; may be NULL).  gamma / beta are
+ *      frozen: no parameter gradients.  Deterministic. */
+int skp_add_layer_norm_ok(int C);
+int skp_add_layer_norm_fwd_f32(const float* d, const float* h, const float* gamma, const float* beta, float* x, float* n,
+                               float* stat, int64_t rows, int C, float eps, void* stream);
+int skp_add_layer_norm_bwd_f32(const float* dn, const float* dskip, const float* x, const float* stat, const float* gamma,
+                               float* dx, int64_t rows, int C, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution of the frozen blocks (diffusers ResnetBlock2D.conv1/conv2, Upsample2D.conv,
  * AutoencoderKL encoder resnets [third party], reached from ptp_utils.py:213-217 and :287) as Winograd F(2x2,3x3)
  * on the fp32 matrix cores.

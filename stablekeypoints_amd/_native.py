@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -48,6 +48,9 @@ SIGNATURES = {
     "skp_group_norm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "skp_group_norm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "skp_add_bias_residual_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "skp_add_layer_norm_ok": [_i],
+    "skp_add_layer_norm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp],
+    "skp_add_layer_norm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
     "skp_conv3x3_filter_f32": [_vp, _vp, _i, _i, _i, _vp],
     "skp_conv3x3_workspace": [_i, _i, _i, _i, _i, _i],
     "skp_conv3x3_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

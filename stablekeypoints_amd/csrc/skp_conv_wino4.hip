@@ -820,8 +820,13 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     a.gx = (int)g.gx;
     a.vtotal = g.tb_per_xcd ? (int)g.gx * S : (int)g.gx;
     // 128-channel form: persistent workgroups, one per CU (the ids are multiples of 8 apart, so a workgroup stays on its XCD's band)
-    static const int persist = [] { const char* e = getenv("SKP_WINO_PERSIST"); return e ? atoi(e) : 256; }();
-    const dim3 grid = c128 ? dim3((unsigned)(persist > 0 ? std::min(a.vtotal, persist & ~7) : a.vtotal), 1, 1)
+    static const int persist = [] {                 // SKP_WINO_PERSIST=0: one workgroup per unit; unset: one per CU of this device
+        if (const char* e = getenv("SKP_WINO_PERSIST")) return atoi(e);
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
+        return ncu;
+    }();
+    const dim3 grid = c128 ? dim3((unsigned)(persist >= 8 ? std::min(a.vtotal, persist & ~7) : a.vtotal), 1, 1)
                            : (g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1));
     if (c128) {                                     // 128 channels x 16 tiles per workgroup
         if (gncoef) {

@@ -13,8 +13,8 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
-from .attention import AttentionBlock, Transformer2DModel
-from .unet import Downsample2D, ResnetBlock2D
+from .attention import AttentionBlock, BasicTransformerBlock, Transformer2DModel
+from .unet import Downsample2D, ResnetBlock2D, UNet2DConditionModel
 
 
 def _resnet_forward(m: ResnetBlock2D):
@@ -30,20 +30,68 @@ def _resnet_forward(m: ResnetBlock2D):
         else:
             h = ops.group_norm_silu(x, m.norm1)                          # (statistics from x's producer when it left them)
             h = ops.conv3x3_auto(h, m.conv1.weight, want_stats=True)     # bias folded into norm2's offset
-        off = m.conv1.bias[None, :].expand(x.shape[0], -1)
-        if m.time_emb_proj is not None and temb is not None:
-            off = off + m.time_emb_proj(F.silu(temb))
+        off = _norm2_offset(m, x.shape[0], temb)
         bias = m.conv2.bias
         res = x
         if m.conv_shortcut is not None:
             # 1x1 shortcut = one batched GEMM on the NCHW planes (no layout transposes); its bias joins conv2's
             res, bias = ops.conv1x1_nobias(x, m.conv_shortcut.weight), _summed_bias(m)
         if ops.conv3x3_gn_fold_ok(h, m.norm2, m.conv2.weight):
-            return ops.conv3x3_gn_silu(h, m.norm2, m.conv2.weight, off=off.contiguous(), bias=bias, residual=res, want_stats=True)
-        h = ops.group_norm_silu(h, m.norm2, off=off.contiguous())
+            return ops.conv3x3_gn_silu(h, m.norm2, m.conv2.weight, off=off, bias=bias, residual=res, want_stats=True)
+        h = ops.group_norm_silu(h, m.norm2, off=off)
         # bias + shortcut in the conv epilogue; its block sums serve the next block's first norm
         return ops.conv3x3_auto(h, m.conv2.weight, bias, residual=res, want_stats=True)
     return forward
+
+
+def _frozen_tag(*params):
+    """Identity of frozen parameters (None when one of them takes gradients: nothing derived from it may be kept)."""
+    if any(p is not None and p.requires_grad for p in params):
+        return None
+    return tuple((p._version, p.data_ptr()) for p in params if p is not None)
+
+
+def _norm2_offset(m: ResnetBlock2D, rows: int, temb):
+    """Per-(row, channel) offset in front of norm2: conv1.bias + time_emb_proj(silu(temb)), contiguous [rows, C].  With the
+    time path kept by `_time_path` below the SAME `temb` tensor arrives every step, and the offset of a frozen block is kept
+    with it (4 small launches per block and step otherwise)."""
+    tag = _frozen_tag(m.conv1.bias, *(m.time_emb_proj.parameters() if m.time_emb_proj is not None else ()))
+    hit = m.__dict__.get("_skp_off")
+    if (hit is not None and tag is not None and hit[0] is temb and hit[1] == (tag, rows)
+            and (temb is None or (hit[2] == temb._version and not temb.requires_grad))):
+        return hit[3]
+    off = m.conv1.bias[None, :].expand(rows, -1)
+    if m.time_emb_proj is not None and temb is not None:
+        off = off + m.time_emb_proj(F.silu(temb))
+    off = off.contiguous()
+    if tag is not None and not off.requires_grad:
+        m.__dict__["_skp_off"] = (temb, (tag, rows), None if temb is None else temb._version, off)
+    return off
+
+
+def _time_path(m: UNet2DConditionModel):
+    """The time embedding of a frozen UNet depends on (timestep values, rows) only, and on this path the timestep is a host
+    value (`scheduler.timesteps[noise_level]`, ptp_utils.py:219-221) that never changes during an optimisation: keep the
+    embedding per key, so every step hands the resnets the same tensor."""
+    orig = m.time_path
+
+    def time_path(sample, timestep, added_cond_kwargs=None):
+        host = not torch.is_tensor(timestep) or (timestep.device.type == "cpu" and timestep.numel() <= 64)
+        tag = _frozen_tag(*m.time_embedding.parameters(), *(m.add_embedding.parameters() if m.add_embedding is not None else ()))
+        if not host or tag is None or added_cond_kwargs is not None:
+            return orig(sample, timestep, added_cond_kwargs)
+        vals = tuple(float(v) for v in (timestep.reshape(-1).tolist() if torch.is_tensor(timestep) else [timestep]))
+        key = (vals, int(sample.shape[0]), tuple(sample.shape[-2:]), sample.device, sample.dtype, tag)
+        memo = m.__dict__.setdefault("_skp_temb", {})
+        hit = memo.get(key)
+        if hit is None:
+            if len(memo) >= 8:
+                memo.clear()
+            with torch.no_grad():
+                hit = orig(sample, timestep, added_cond_kwargs)
+            memo[key] = hit
+        return hit
+    return time_path
 
 
 def _summed_bias(m: ResnetBlock2D):
@@ -78,6 +126,22 @@ def _transformer_forward(m: Transformer2DModel):
             t = blk(t, context=context)
         t = ops.linear_auto(t, m.proj_out.weight.flatten(1), m.proj_out.bias)
         return ops.tokens_to_nchw_add(t, x)
+    return forward
+
+
+def _block_forward(m: BasicTransformerBlock):
+    """`attn(norm(h)) + h` three times over: every residual add rides in the NEXT norm's kernel (ops.add_layer_norm), and the
+    gradient that reaches the residual stream from its later uses is added inside that norm's input-gradient kernel."""
+    orig = m.forward
+
+    def forward(h, context=None):
+        if not (ops.add_layer_norm_supported(h, m.norm1) and ops.add_layer_norm_supported(h, m.norm2)
+                and ops.add_layer_norm_supported(h, m.norm3)):
+            return orig(h, context=context)
+        h, n = ops.add_layer_norm(None, h, m.norm1)
+        h, n = ops.add_layer_norm(m.attn1(n), h, m.norm2)
+        h, n = ops.add_layer_norm(m.attn2(n, context=context), h, m.norm3)
+        return m.ff(n) + h
     return forward
 
 
@@ -133,6 +197,9 @@ def _linear_forward(m: torch.nn.Linear):
 def fuse_norms(module: torch.nn.Module) -> int:
     n = 0
     for mod in module.modules():
+        if isinstance(mod, UNet2DConditionModel) and "time_path" not in mod.__dict__:
+            mod.time_path = _time_path(mod)
+            continue
         if ops.EMULATED_F32 and isinstance(mod, torch.nn.Linear) and "forward" not in mod.__dict__:
             mod.forward = _linear_forward(mod)      # experiment: frozen Linear layers on the split-bf16 GEMM
             continue
@@ -146,6 +213,9 @@ def fuse_norms(module: torch.nn.Module) -> int:
             continue
         if isinstance(mod, AttentionBlock) and "forward" not in mod.__dict__:
             mod.forward = _vae_attention_forward(mod); n += 1
+            continue
+        if isinstance(mod, BasicTransformerBlock) and "forward" not in mod.__dict__:
+            mod.forward = _block_forward(mod); n += 1
             continue
         if isinstance(mod, ResnetBlock2D) and "forward" not in mod.__dict__:
             mod.forward = _resnet_forward(mod); n += 1

@@ -246,7 +246,8 @@ class UNet2DConditionModel(nn.Module):
         return {"text_embeds": torch.zeros(b, pooled, device=sample.device, dtype=sample.dtype),
                 "time_ids": torch.tensor([[hh, ww, 0.0, 0.0, hh, ww]], device=sample.device, dtype=sample.dtype).expand(b, -1)}
 
-    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
+    def time_path(self, sample, timestep, added_cond_kwargs=None):
+        """Time (+ SDXL micro-conditioning) embedding [rows, temb_ch]: independent of the latents and of the text embedding."""
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], device=sample.device)
         timestep = timestep.reshape(-1).to(sample.device).expand(sample.shape[0])
@@ -256,6 +257,10 @@ class UNet2DConditionModel(nn.Module):
             ids = cond["time_ids"]
             tids = timestep_embedding(ids.reshape(-1), self._add_t_dim).reshape(ids.shape[0], -1)
             temb = temb + self.add_embedding(torch.cat([cond["text_embeds"], tids.to(sample.dtype)], dim=-1))
+        return temb
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None):
+        temb = self.time_path(sample, timestep, added_cond_kwargs)
         h = self.conv_in(sample)
         skips = [h]
         for blk in self.down_blocks:

@@ -658,6 +658,64 @@ def add_bias_residual(a, b, bias):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# residual add + LayerNorm of the transformer blocks, one pass per direction (csrc/skp_layer_norm.hip)
+# ---------------------------------------------------------------------------------------------------------
+ADD_LN = os.environ.get("SKP_ADD_LN", "1") != "0"                # A/B switch
+
+
+def add_layer_norm_supported(h, norm: torch.nn.LayerNorm) -> bool:
+    return bool(ADD_LN and h.is_cuda and h.dtype == torch.float32 and len(norm.normalized_shape) == 1
+                and norm.elementwise_affine and norm.bias is not None and h.shape[-1] == norm.normalized_shape[0]
+                and not (norm.weight.requires_grad or norm.bias.requires_grad)
+                and N.lib().skp_add_layer_norm_ok(int(h.shape[-1])))
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """(x, n) = (d + h, LayerNorm(d + h)); with d None: (h, LayerNorm(h)).  The first output carries the residual stream on,
+    so the gradient that reaches it from its later uses is added inside the norm's input-gradient kernel instead of a
+    separate accumulation pass; d and h both receive that sum."""
+
+    @staticmethod
+    def forward(ctx, d, h, weight, bias, eps):
+        h = _dev(h, "h")
+        C = h.shape[-1]
+        rows = h.numel() // C
+        n = torch.empty_like(h)
+        stat = torch.empty(rows, 2, device=h.device, dtype=torch.float32)
+        if d is not None:
+            d = _dev(d, "d")
+            x = torch.empty_like(h)
+        else:
+            x = h
+        N.check(N.lib().skp_add_layer_norm_fwd_f32(d.data_ptr() if d is not None else None, h.data_ptr(), weight.data_ptr(),
+                                                   bias.data_ptr(), x.data_ptr() if d is not None else None, n.data_ptr(),
+                                                   stat.data_ptr(), rows, C, float(eps), _stream()), "skp_add_layer_norm_fwd_f32")
+        ctx.save_for_backward(x, stat, weight)
+        ctx.has_d = d is not None
+        return x, n                                  # d None: x is the input itself (autograd hands back an alias)
+
+    @staticmethod
+    def backward(ctx, gx, gn):
+        x, stat, weight = ctx.saved_tensors
+        C = x.shape[-1]
+        if gn is None:
+            dx = gx
+        else:
+            gn = _dev(gn, "gn")
+            gx = _dev(gx, "gx") if gx is not None else None
+            dx = torch.empty_like(x)
+            N.check(N.lib().skp_add_layer_norm_bwd_f32(gn.data_ptr(), gx.data_ptr() if gx is not None else None, x.data_ptr(),
+                                                       stat.data_ptr(), weight.data_ptr(), dx.data_ptr(), x.numel() // C, C,
+                                                       _stream()), "skp_add_layer_norm_bwd_f32")
+        return (dx if ctx.has_d else None), dx, None, None, None
+
+
+def add_layer_norm(d, h, norm: torch.nn.LayerNorm):
+    """Returns (d + h, norm(d + h)); d may be None -> (h, norm(h))."""
+    return AddLayerNormFn.apply(d, h, norm.weight, norm.bias, norm.eps)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # 3x3 / stride 1 / pad 1 convolutions of the frozen blocks: Winograd F(2x2,3x3) on the fp32 matrix cores.
 # ---------------------------------------------------------------------------------------------------------
 def conv3x3_supported(x_shape, w_shape, need_grad=True):

@@ -573,3 +573,44 @@ def test_cached_latents_reproduce_the_uncached_trajectory(tiny):
     # Adam normalises near-zero gradient elements, so last-bit differences of the encoder (batch of 2 rows instead of 4) show up as
     # ~1e-4 of one step (lr = 5e-3) on a handful of elements
     torch.testing.assert_close(runs[1], runs[0], rtol=1e-4, atol=5e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 50, 320), (3, 17, 640), (2, 9, 1280), (4, 5, 64), (2, 7, 32), (1, 3, 1024), (2, 4097, 320)])
+@pytest.mark.parametrize("with_d", [True, False])
+def test_add_layer_norm_fwd_bwd_vs_fp64(shape, with_d):
+    """Residual add + LayerNorm in one pass per direction (skp_add_layer_norm_*): both outputs and the gradients of d and h --
+    the loss uses the carried-on sum AND the normalised rows, as a transformer block does -- against fp64 torch; a repeat gives
+    the same bits.  Row widths of all three trees (320 / 640 / 1280: 16 / 32 / 64 lanes x 5 float4) and the small test trees."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(131)
+    C = shape[-1]
+    norm = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g) * 0.5 + 1.0)
+        norm.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    norm.requires_grad_(False)
+    h = torch.randn(shape, generator=g) * 2 + 0.7
+    d = torch.randn(shape, generator=g) if with_d else None
+    w1, w2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    hd = h.double().requires_grad_(True)
+    dd = d.double().requires_grad_(True) if with_d else None
+    xr = hd + dd if with_d else hd
+    nr = torch.nn.functional.layer_norm(xr, (C,), norm.weight.double(), norm.bias.double(), norm.eps)
+    ((xr * w1.double()).sum() + (nr * w2.double()).sum()).backward()
+    norm = norm.cuda()
+    assert ops.add_layer_norm_supported(h.cuda(), norm)
+    outs = []
+    for _ in range(2):
+        hg = h.cuda().requires_grad_(True)
+        dg = d.cuda().requires_grad_(True) if with_d else None
+        x, n = ops.add_layer_norm(dg, hg, norm)
+        ((x * w1.cuda()).sum() + (n * w2.cuda()).sum()).backward()
+        outs.append((x.detach(), n.detach(), hg.grad, dg.grad if with_d else None))
+    x, n, gh, gd = outs[0]
+    torch.testing.assert_close(x.cpu().double(), xr.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(n.cpu().double(), nr.detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(gh.cpu().double(), hd.grad, rtol=2e-5, atol=2e-5)
+    if with_d:
+        torch.testing.assert_close(gd.cpu().double(), dd.grad, rtol=2e-5, atol=2e-5)
+    for a, b in zip(outs[0], outs[1]):
+        assert a is None or torch.equal(a, b)
