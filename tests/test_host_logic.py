@@ -297,3 +297,37 @@ def test_linear_and_qkv_dispatch_rules_on_cpu():
         assert torch.equal(a, torch.nn.functional.linear(x, w))
     y = ops.conv1x1_nobias(torch.randn(2, 8, 3, 5, generator=g), torch.randn(4, 8, 1, 1, generator=g))
     assert y.shape == (2, 4, 3, 5)
+
+
+def test_constant_time_path_is_kept_and_invalidated():
+    """`fused._time_path`: with a host timestep and a frozen time MLP the UNet hands every step the SAME time-embedding tensor
+    (the resnets key their kept norm2 offsets on it); another timestep, an in-place weight change or a parameter that takes
+    gradients give a fresh one; values equal the module's own `time_path` bit for bit."""
+    from stablekeypoints_amd.ldm.fused import _norm2_offset, fuse_norms
+    from stablekeypoints_amd.ldm.unet import ResnetBlock2D
+    from stablekeypoints_amd.optimize_token import load_ldm
+    ldm, _, _ = load_ldm("cpu", "tiny", feature_upsample_res=32)
+    unet = ldm.unet
+    fuse_norms(unet)                                              # (load_ldm only does this on a GPU)
+    own = type(unet).time_path
+    x = torch.randn(2, 4, 16, 16)
+    t = ldm.scheduler.timesteps[-1]
+    a, b = unet.time_path(x, t.repeat(2)), unet.time_path(x, t.repeat(2))
+    assert a is b and not a.requires_grad and torch.equal(a, own(unet, x, t.repeat(2)))
+    c = unet.time_path(x, ldm.scheduler.timesteps[0].repeat(2))
+    assert c is not a and not torch.equal(c, a)
+    assert unet.time_path(x[:1], t.repeat(1)).shape[0] == 1      # rows are part of the key
+    res = next(m for m in unet.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None)
+    o1, o2 = _norm2_offset(res, 2, a), _norm2_offset(res, 2, a)
+    assert o1 is o2 and o1.is_contiguous()
+    assert torch.equal(o1, res.conv1.bias[None] + res.time_emb_proj(torch.nn.functional.silu(a)))
+    assert _norm2_offset(res, 2, c) is not o1                    # another embedding tensor: recomputed
+    with torch.no_grad():
+        unet.time_embedding.linear_1.weight.mul_(1.5)            # version bump
+        res.conv1.bias.add_(1.0)
+    d = unet.time_path(x, t.repeat(2))
+    assert d is not a and torch.equal(d, own(unet, x, t.repeat(2))) and not torch.equal(d, a)
+    assert not torch.equal(_norm2_offset(res, 2, a), o1)         # the block's own parameters changed
+    unet.time_embedding.linear_1.weight.requires_grad_(True)
+    e1, e2 = unet.time_path(x, t.repeat(2)), unet.time_path(x, t.repeat(2))
+    assert e1 is not e2 and e1.requires_grad
