@@ -9,7 +9,7 @@ CLASSES = [
     ("skp conv3x3 (Winograd stride 1 + direct stride 2)", ("skp_wino", "skp_conv_s2")),
     ("skp flash attention (self + long-key cross)", ("skp_self_attn", "skp_fa2_")),
     ("skp attention map fwd/bwd (north-star kernel)", ("skp_attn_map", "skp_map_")),
-    ("skp fused GroupNorm+SiLU / bias+residual", ("skp_group_norm", "skp_gn_", "skp_add_bias")),
+    ("skp fused GroupNorm+SiLU / bias+residual / add+LayerNorm", ("skp_group_norm", "skp_gn_", "skp_add_bias", "skp_add_ln")),
     ("skp cross-attn (T<=128) / selection / loss / small gemm / geglu / layout", ("skp_",)),
     ("conv (MIOpen)", ("igemm", "Igemm", "conv", "Conv", "winograd", "Winograd", "gridwise_convolution", "naive_conv",
                        "SubTensorOpWithScalar", "batched_transpose", "Im2Col", "Col2Im", "kernel_grouped_conv")),
