@@ -439,11 +439,19 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     auto gn_fetch = [&](int cin0) { if (GNF) gcoef = skp_buf_load_f32x2(crs, coff, cin0 * 8, 0); };
     auto gn_row = [&](int i) {                       // normalise + SiLU row i of the freshly loaded patch
         if (GNF) {
+            // v = x * s + h;  silu(v) = v * rcp(1 + 2^(-v log2 e)): the exponent is its own fma of x, and the quotient is
+            // v_rcp_f32 (1 ulp) -- an IEEE division here is ten VALU instructions per value, 360 per stage and thread, all of
+            // them added to the MFMA time
             const bool rv = (rowmask >> i) & 1u;
             const float sc = rv ? gcoef[0] : 0.f, sh = rv ? gcoef[1] : 0.f;
-            auto act = [](float x, float s, float h) { const float v = fmaf(x, s, h); return v / (1.0f + __expf(-v)); };
-            d[i][0][0] = act(d[i][0][0], lok ? sc : 0.f, lok ? sh : 0.f);
-            d[i][0][1] = act(d[i][0][1], rok ? sc : 0.f, rok ? sh : 0.f);
+            const float sl = lok ? sc : 0.f, hl = lok ? sh : 0.f, sr = rok ? sc : 0.f, hr = rok ? sh : 0.f;
+            auto act = [](float x, float s, float h) {
+                const float v = fmaf(x, s, h);
+                const float e = __builtin_amdgcn_exp2f(fmaf(x, -SKP_LOG2E * s, -SKP_LOG2E * h));
+                return v * __builtin_amdgcn_rcpf(1.0f + e);
+            };
+            d[i][0][0] = act(d[i][0][0], sl, hl);
+            d[i][0][1] = act(d[i][0][1], sr, hr);
             d[i][1][0] = act(d[i][1][0], sc, sh); d[i][1][1] = act(d[i][1][1], sc, sh);
             d[i][2][0] = act(d[i][2][0], sc, sh); d[i][2][1] = act(d[i][2][1], sc, sh);
         }
