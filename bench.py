@@ -578,7 +578,11 @@ def main():
                                    f"{image_size}x{image_size}, batch {per_rank} images/rank/step x 2 views, "
                                    f"T={a.tokens} tokens x {width}, R={a.res}, top_k={a.top_k} of {a.candidates}, fp32 end to end",
                        "global_batch": global_batch, "images_per_rank": per_rank, "tokens": a.tokens, "embedding_dim": width,
-                       "feature_upsample_res": a.res, "parallelism": f"dp{world}"},
+                       "feature_upsample_res": a.res, "parallelism": f"dp{world}",
+                       "kept_across_steps": "functions of the frozen weights and the fixed timestep only: transformed convolution "
+                                            "filters, summed biases, the time embedding and the per-resnet offsets derived from it "
+                                            "(ldm/fused.py); nothing that depends on an image, the noise or the embedding "
+                                            "(latents are re-encoded every step: --cache-latents is a separate experiment line)"},
             # dominant kernel of the step by time: the Winograd conv of the frozen blocks, priced on the
             # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
             "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {min(image_size, 512)}^2, "
