@@ -539,6 +539,8 @@ def main():
         value = global_batch * a.steps / elapsed
         issue1, issue2 = ops.mfma_issue_rate(1, device=dev), ops.mfma_issue_rate(2, device=dev)
         conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}")
+        if conv_traffic is None:                                 # committed passes from before the kernel became persistent: same
+            conv_traffic, conv_src = measured_traffic("skp_wino4_conv_c128_kernel@grid2097152")    # launch shape, one workgroup per unit
         map_kernel = "skp_attn_map_fwd_wide_kernel" if ops.map_wide_supported(a.tokens, a.res) else "skp_attn_map_fwd_kernel"
         map_traffic, map_src = measured_traffic(map_kernel)
         live, map_bwd_traffic = None, None
