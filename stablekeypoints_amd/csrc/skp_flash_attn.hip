@@ -612,8 +612,10 @@ __global__ __launch_bounds__(256) void skp_fa2_rowdot_kernel(const float* __rest
     Dbuf[i] = acc;
 }
 
-template <int D, int MINB, bool OVL, int NQ>
-__global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
+// NW = 4: a wave owns 32 keys of the block (two 16-key tiles); NW = 8: 16 keys (one tile) -- half the K / V fragments and dK / dV
+// accumulators per wave, so the 80-wide heads fit two waves per SIMD without spilled registers at 64-query tiles.
+template <int D, int MINB, bool OVL, int NQ, int NW = 4>
+__global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqp, float* __restrict__ dk,
@@ -626,7 +628,9 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
     float* Ks = smem + X::OFF_K;
     float* Xs = smem + X::OFF_X;
     float* Ls = smem + X::OFF_S;                              // lse2[QT] | D[QT] (at 0 and 64)
+    constexpr int TT = 8 / NW, KW = 16 * TT, NTH = 64 * NW;    // key tiles per wave, keys per wave, threads
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+    const int stid = tid < 256 ? tid : (1 << 24);              // tile staging is dealt to the first 256 threads
     const int kb = blockIdx.x, b = blockIdx.z, h = blockIdx.y, C = H * D;
     const int t0 = kb * X::KB;
     const size_t hoff = (size_t)b * N * C + (size_t)h * D;     // self-attention: q, k, v, dout share [B, N, C]
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
     const float sl2 = scale * SKP_LOG2E;
 
     // the block's K rows into LDS (raw, for the dQ product); K / V fragments of this wave's 32 keys into registers
-    for (int idx = tid; idx < X::KB * F::Q4; idx += 256) {
+    for (int idx = tid; idx < X::KB * F::Q4; idx += NTH) {
         const int t = idx / F::Q4, c4 = idx - t * F::Q4;
         f32x4 val = {0.f, 0.f, 0.f, 0.f};
         if (t0 + t < Nk) val = *(const f32x4*)(k + ((size_t)b * Nk + t0 + t) * C + h * D + c4 * 4);
@@ -644,11 +648,11 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
     }
     // OVL (64-wide heads): the K fragments of the S product are read from the block's LDS copy (raw; the scale moves into
     // the exp2 argument) instead of living in registers -- with them the kernel does not fit two waves per SIMD
-    f32x2 kf[OVL ? 1 : 2][OVL ? 1 : F::D8], vf[2][F::D8];
-    int trow[2];
+    f32x2 kf[OVL ? 1 : TT][OVL ? 1 : F::D8], vf[TT][F::D8];
+    int trow[TT];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int t = t0 + 32 * wave + 16 * tt + i16;
+    for (int tt = 0; tt < TT; ++tt) {
+        const int t = t0 + KW * wave + 16 * tt + i16;
         trow[tt] = t;
         const size_t ro = ((size_t)b * Nk + (t < Nk ? t : Nk - 1)) * C + h * D + 2 * g;
 #pragma unroll
@@ -657,11 +661,11 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
             vf[tt][jj] = *(const f32x2*)(v + ro + 8 * jj);
         }
     }
-    f32x4 dka[F::CT][2], dva[F::CT][2];
+    f32x4 dka[F::CT][TT], dva[F::CT][TT];
 #pragma unroll
     for (int ct = 0; ct < F::CT; ++ct)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) { dka[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int tt = 0; tt < TT; ++tt) { dka[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[ct][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     auto fetch_stats = [&](int q0) -> float {
         const int i = tid & 63, n = q0 + i;
@@ -670,11 +674,11 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         return tid < 64 ? lse[soff + n] * SKP_LOG2E : Dbuf[soff + n];
     };
     FA2Stage<D> stg;
-    stg.init(C, tid, X::QT);
+    stg.init(C, stid, X::QT);
     f32x4 qr[F::U], dr[F::U];
     float st = fetch_stats(0);
-    fa2_fetch_tile<D>(qr, qg, C, 0, N, stg, tid);
-    fa2_fetch_tile<D>(dr, dog, C, 0, N, stg, tid);
+    fa2_fetch_tile<D>(qr, qg, C, 0, N, stg, stid);
+    fa2_fetch_tile<D>(dr, dog, C, 0, N, stg, stid);
     fa2_put<D>(Qs, qr, stg);
     fa2_put<D>(dOs, dr, stg);
     if (tid < 128) Ls[tid] = st;
@@ -686,17 +690,17 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         const bool more = q0 + X::QT < N;
         if (!OVL && more) {                                     // next query tile: in flight under this tile's MFMAs
             st = fetch_stats(q0 + X::QT);
-            fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, tid);
-            fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, tid);
+            fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, stid);
+            fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, stid);
         }
-        f32x4 s[NQ][2], dp[NQ][2];
+        f32x4 s[NQ][TT], dp[NQ][TT];
 #pragma unroll
         for (int nt = 0; nt < NQ; ++nt)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if (OVL) fa2_rowdot_lds<D, NQ, 2>(Qs, Ks + 32 * wave * F::LDK, s, i16, g);   // raw S[n][t]
-        else fa2_rowdot<D, NQ, 2>(Qs, (const f32x2 (&)[2][F::D8])kf, s, i16, g);    // S[n][t] (scaled, log2 units)
-        fa2_rowdot<D, NQ, 2>(dOs, vf, dp, i16, g);              // dP[n][t]
+            for (int tt = 0; tt < TT; ++tt) { s[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (OVL) fa2_rowdot_lds<D, NQ, TT>(Qs, Ks + KW * wave * F::LDK, s, i16, g);   // raw S[n][t]
+        else fa2_rowdot<D, NQ, TT>(Qs, (const f32x2 (&)[TT][F::D8])kf, s, i16, g);    // S[n][t] (scaled, log2 units)
+        fa2_rowdot<D, NQ, TT>(dOs, vf, dp, i16, g);              // dP[n][t]
 #pragma unroll
         for (int nt = 0; nt < NQ; ++nt) {
             const f32x4 l4 = *(const f32x4*)(Ls + 16 * nt + 4 * g);
@@ -704,14 +708,14 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
+                for (int tt = 0; tt < TT; ++tt) {
                     const float pr = __builtin_amdgcn_exp2f(OVL ? __builtin_fmaf(s[nt][tt][r], sl2, -l4[r]) : s[nt][tt][r] - l4[r]);
                     s[nt][tt][r] = pr;                                   // P
                     dp[nt][tt][r] = pr * (dp[nt][tt][r] - d4[r]);        // dS
                 }
         }
-        fa2_colacc<D, NQ, 2>(dOs, s, dva, i16, g);               // dV^T[c][t] += sum_n dO[n][c] P[n][t]
-        fa2_colacc<D, NQ, 2>(Qs, dp, dka, i16, g);               // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
+        fa2_colacc<D, NQ, TT>(dOs, s, dva, i16, g);               // dV^T[c][t] += sum_n dO[n][c] P[n][t]
+        fa2_colacc<D, NQ, TT>(Qs, dp, dka, i16, g);               // dK^T[c][t] += sum_n Q[n][c] dS[n][t]
         // dS -> LDS, [query n][key of the block]
         if (OVL) __syncthreads();                              // the exchange buffer lies over Q | dO: everyone is done reading them
 #pragma unroll
@@ -719,12 +723,12 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-                    Xs[(16 * nt + 4 * g + r) * X::LDX + 32 * wave + 16 * tt + i16] = dp[nt][tt][r];
+                for (int tt = 0; tt < TT; ++tt)
+                    Xs[(16 * nt + 4 * g + r) * X::LDX + KW * wave + 16 * tt + i16] = dp[nt][tt][r];
         if (OVL && more) {                                     // the score registers are free now: fetch the next tile into them
             st = fetch_stats(q0 + X::QT);
-            fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, tid);
-            fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, tid);
+            fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, stid);
+            fa2_fetch_tile<D>(dr, dog, C, q0 + X::QT, N, stg, stid);
         }
         __syncthreads();                                       // dS complete; everyone is done with this tile's Q / dO
         if (!OVL && more) {
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
             if (tid < 128) Ls[tid] = st;
         }
         // dQ^T[c][n] over the block's 128 keys
-        if (NQ == 4) {                                         // wave w: queries 16 w .. 16 w + 15, all channel tiles (one dS read per 16 keys)
+        if (NQ == 4 && NW == 4) {                              // wave w: queries 16 w .. 16 w + 15, all channel tiles (one dS read per 16 keys)
             f32x4 dqa[F::CT];
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) dqa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -758,11 +762,11 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
                     if (c0 < D) *(f32x4*)(drow + c0) = dqa[ct];
                 }
             }
-        } else {                                               // NQ query tiles x CT channel tiles dealt round-robin to the four waves
+        } else {                                               // NQ query tiles x CT channel tiles dealt round-robin to the waves
             constexpr int NPAIR = NQ * F::CT;
 #pragma unroll
-            for (int j = 0; j < (NPAIR + 3) / 4; ++j) {
-                const int pair = wave + 4 * j;                  // wave-uniform
+            for (int j = 0; j < (NPAIR + NW - 1) / NW; ++j) {
+                const int pair = wave + NW * j;                 // wave-uniform
                 if (pair < NPAIR) {
                     const int ct = pair / NQ, qt = pair - ct * NQ;
                     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(256, MINB) void skp_fa2_bwd_fused_kernel(const floa
         }
     }
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
         const int t = trow[tt];
         if (t < Nk) {
             const size_t ro = ((size_t)b * Nk + t) * C + h * D;
@@ -897,9 +901,8 @@ static bool fa2_fused_ok(int Bk, int B, int H, int N, int Nk, int d) {
     const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
     if (e && e[0] == '0') return false;
     // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 64-wide: two per CU with the dS exchange laid over the
-    // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: the same with
-    // 48-query tiles (75.8 KB; 57 spilled registers): 0.42 -> 0.55 at N = 1024, 0.69 at N = 4096 (SKP_FA2_D80=1: the
-    // 64-query form at one workgroup per CU, 0.52 / 0.64).
+    // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: 64-query tiles on
+    // eight waves (round 3): 0.42 (two kernels) -> 0.53 (48-query four-wave form, round 2) -> 0.59 at N = 1024, 0.72 at N = 4096.
     if (!((d == 40 || d == 64 || d == 80) && Bk == B && N == Nk && N >= 1024)) return false;   // the big self-attention layers
     // the single-pass form keeps ceil(Nk / 128) copies of dQ as partials: O(B N^2 C / 128) floats (13 GB at SD-2.1 768^2,
     // B = 16).  Past 2 GiB the two-kernel form (B*H*N floats of scratch) takes over.
@@ -914,7 +917,7 @@ int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     return fl * (int64_t)sizeof(float);
 }
 
-template <int D, int MINB, bool OVL, int NQ>
+template <int D, int MINB, bool OVL, int NQ, int NW = 4>
 static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                 const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk,
                                 float scale, hipStream_t st) {
@@ -922,7 +925,7 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     const size_t lds = (size_t)X::LDS_FLOATS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
@@ -933,7 +936,7 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     int rc = skp_launch_status();
     if (rc) return rc;
     const int nkb = (Nk + X::KB - 1) / X::KB;
-    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ>), dim3(nkb, H, B), dim3(256), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
+    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ, NW>), dim3(nkb, H, B), dim3(64 * NW), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
                        N, Nk, scale);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -954,8 +957,13 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
     if (allow_fused && fa2_fused_ok(Bk, B, H, N, Nk, d)) {
         if (d == 40) return fa2_launch_bwd_fused<40, 2, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
         if (d == 64) return fa2_launch_bwd_fused<64, 2, true, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
-        { const char* e8 = getenv("SKP_FA2_D80"); if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st); }
-        return fa2_launch_bwd_fused<80, 2, true, 3>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        // 80-wide heads: 64-query tiles on EIGHT waves (16 keys each: half the K / V fragments and dK / dV accumulators per wave,
+        // 224 registers, nothing spilled, two waves per SIMD at one 120 KB workgroup per CU).  SKP_FA2_D80=3: the 48-query
+        // four-wave form of round 2 (two workgroups per CU, 57 spilled registers), =1: 64 queries on four waves (one per SIMD)
+        { const char* e8 = getenv("SKP_FA2_D80");
+          if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+          if (e8 && e8[0] == '3') return fa2_launch_bwd_fused<80, 2, true, 3>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st); }
+        return fa2_launch_bwd_fused<80, 1, false, 4, 8>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
     }
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
     return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
