@@ -182,6 +182,15 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert lib.skp_select_tokens(p, p, 77, 128, 25, 1, p, p, null) == -2                  # top_k < 2
     assert lib.skp_token_stats_f32(p, 77, 128, 9, 2.0, 1e-5, p, null, null, null) == -2         # too many subjects
     assert lib.skp_losses_fwd_f32(p, p, p, 10, 77, 128, p, 1, 2.0, None, p, p, p, p, null) == -1
+    # round 3 entry points
+    assert lib.skp_add_layer_norm_ok(320) == 1 and lib.skp_add_layer_norm_ok(1280) == 1 and lib.skp_add_layer_norm_ok(30) == 0
+    assert lib.skp_add_layer_norm_fwd_f32(null, null, p, p, null, p, p, 4, 320, 1e-5, null) == -1      # no input
+    assert lib.skp_add_layer_norm_fwd_f32(p, p, p, p, null, p, p, 4, 320, 1e-5, null) == -1         # d without a place for d + h
+    assert lib.skp_add_layer_norm_fwd_f32(null, p, p, p, null, p, p, 4, 30, 1e-5, null) == -2        # row width without a plan
+    assert lib.skp_add_layer_norm_bwd_f32(p, null, p, p, p, null, 4, 320, null) == -1
+    assert lib.skp_unwarp_accumulate_f32(null, p, 1, 1, 32, 64, p, p, 1, null) < 0
+    assert lib.skp_conv3x3_f4_gn_ok(8, 128, 128, 512, 512) == 1 and lib.skp_conv3x3_f4_gn_ok(8, 320, 320, 64, 64) == 0   # one channel group only
+    assert lib.skp_conv3x3_f4_gn_f32(p, p, null, null, p, null, null, 8, 128, 128, 512, 512, null) == -1              # no coefficients
 
 
 def test_tuning_module_is_inert_without_a_gpu():
