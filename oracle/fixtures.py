@@ -98,3 +98,9 @@ def sharp_entropy_maps(maps):
     """The second map family of G3b (oracle/gen_golden.py): per-token entropies spread far apart."""
     n = maps.shape[0]
     return torch.softmax((maps * 40.0).view(n, -1) * torch.linspace(0.2, 3.0, n)[:, None], dim=-1).view_as(maps).contiguous()
+
+
+# G13: the reference's keypoint_regressor.precompute_all_keypoints (:111-198) over a 5-image keypoint dataset stub on the
+# same reduced-width model (the embedding after G11's last step, G12's voted indices): per image `aug_iters` affine
+# views -> maps of the voted tokens at the reference's hard-wired 512 x 512 -> arg-max / weighted-average locations.
+KPTS_CASE = dict(size=128, n_images=5, aug_iters=3, n_kpts=3, seed=91)

@@ -370,6 +370,10 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g11_reference_trajectory_tiny.npz"), **g11)
     np.savez_compressed(os.path.join(OUT, "g12_reference_best_indices_tiny.npz"), **g12)
 
+    # ---------------- G13: the reference's OWN keypoint_regressor.precompute_all_keypoints (:111-198) ----------------------
+    g13 = reference_keypoints(ptp_utils, inv, g11, g12)
+    np.savez_compressed(os.path.join(OUT, "g13_reference_keypoints_tiny.npz"), **g13)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden written to", OUT, "total bytes", tot)
 
@@ -471,5 +475,89 @@ def reference_loops(optimize, ptp_utils, inv):
     return g11, g12
 
 
+def reference_keypoints(ptp_utils, inv, g11, g12, hook="reference", controllers=None, ldm=None):
+    """Drive the reference's `precompute_all_keypoints` (dataset loop -> `run_image_with_context_augmented` ->
+    `find_max_pixel / 512` or `pixel_from_weighted_avg / 512`) on CPU over a keypoint-dataset stub patched in for
+    `taichi.TrainRegSet`, once per `max_loc_strategy` from the same seed (same loader order, noise and thetas), recording
+    every draw.  `hook="reference"`: the reference's own hook on the reduced-width model (the golden).  With `ldm` /
+    `controllers` given (oracle/check_dropin.py) the same call runs on THOSE objects instead."""
+    import types as _types
+    from oracle.fixtures import LOOP_CASE, KPTS_CASE
+    from unsupervised_keypoints import keypoint_regressor
+    lc, kc = LOOP_CASE, KPTS_CASE
+    if ldm is None:
+        from stablekeypoints_amd.ldm.pipeline import StableDiffusionPipeline
+        from stablekeypoints_amd.ldm.scheduler import DDIMScheduler
+        sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                            set_alpha_to_one=False)
+        sch.set_timesteps(50)
+        ldm = StableDiffusionPipeline.from_pretrained("tiny", scheduler=sch)
+        for pm in list(ldm.unet.parameters()) + list(ldm.vae.parameters()):
+            pm.requires_grad = False
+        ctrl = ptp_utils.AttentionStore()
+        controllers = {torch.device("cpu"): ctrl}
+        ptp_utils.register_attention_control(ldm.unet, ctrl, feature_upsample_res=lc["R"])
+    served = []
+
+    class KeypointImages(torch.utils.data.Dataset):
+        def __init__(self, data_root=None, image_size=512, **_):
+            gen = torch.Generator().manual_seed(kc["seed"])
+            self.data = torch.rand(kc["n_images"], 3, kc["size"], kc["size"], generator=gen)
+            self.kpts = torch.rand(kc["n_images"], kc["n_kpts"], 2, generator=gen)
+
+        def __len__(self):
+            return self.data.shape[0]
+
+        def __getitem__(self, i):
+            served.append(int(i))
+            return {"img": self.data[i], "kpts": self.kpts[i]}
+
+    drawn, thetas = [], []
+    real_randn_like, real_call = torch.randn_like, inv.RandomAffineWithInverse.__call__
+    real_set = keypoint_regressor.taichi.TrainRegSet
+
+    def rec_randn_like(x, *a, **k):
+        out = real_randn_like(x, *a, **k)
+        drawn.append(out.clone())
+        return out
+
+    def rec_call(self, img, theta=None):
+        out = real_call(self, img, theta)
+        thetas.append(self.last_params["theta"].clone())
+        return out
+
+    context = torch.from_numpy(g11["context"][-1:]).clone()
+    indices = torch.from_numpy(g12["indices"]).clone()
+    out = {"indices": indices.numpy()}
+    torch.randn_like, inv.RandomAffineWithInverse.__call__ = rec_randn_like, rec_call
+    keypoint_regressor.taichi.TrainRegSet = KeypointImages
+    try:
+        for strategy in ("argmax", "weighted_avg"):
+            args = _types.SimpleNamespace(
+                dataset_name="taichi", dataset_loc="", device="cpu", layers=[0, 1, 2, 3], noise_level=-1,
+                augmentation_iterations=kc["aug_iters"], augment_degrees=15, augment_scale=[0.8, 1.0],
+                augment_translate=[0.25, 0.25], save_folder="outputs", max_num_points=50_000, max_loc_strategy=strategy)
+            served.clear(); drawn.clear(); thetas.clear()
+            torch.manual_seed(kc["seed"] + 1)
+            src, tgt, vis = keypoint_regressor.precompute_all_keypoints(ldm, context, indices, args, controllers, 1)
+            assert vis is None and len(served) == kc["n_images"] and len(drawn) == len(thetas) == kc["n_images"] * kc["aug_iters"]
+            if strategy == "argmax":
+                out.update(order=np.array(served), noise=torch.cat(drawn).numpy(), thetas=torch.cat(thetas).numpy(),
+                           source_argmax=src.numpy(), target=tgt.numpy())
+            else:
+                assert np.array_equal(out["order"], np.array(served)) and np.array_equal(out["thetas"], torch.cat(thetas).numpy())
+                out["source_weighted"] = src.numpy()
+    finally:
+        torch.randn_like, inv.RandomAffineWithInverse.__call__ = real_randn_like, real_call
+        keypoint_regressor.taichi.TrainRegSet = real_set
+    return out
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":          # only the newest fixture (the others are unchanged inputs to it)
+        _o = import_reference()
+        g11_ = dict(np.load(os.path.join(OUT, "g11_reference_trajectory_tiny.npz")))
+        g12_ = dict(np.load(os.path.join(OUT, "g12_reference_best_indices_tiny.npz")))
+        np.savez_compressed(os.path.join(OUT, "g13_reference_keypoints_tiny.npz"), **reference_keypoints(_o[1], _o[4], g11_, g12_))
+    else:
+        main()

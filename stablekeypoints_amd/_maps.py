@@ -12,20 +12,87 @@ from . import ops
 class FusedAttn:
     """Handle stored by the hooked cross-attention instead of the (B*h, R^2, T) probability tensor of
     ptp_utils.py:535-538.  Holds q = to_q(x) [B,s^2,C] and k = to_k(context) [B,T,C] (with autograd
-    history) -- 8 MB per forward at SD-1.5/512^2 instead of the reference's 161 MB."""
+    history) -- 8 MB per forward at SD-1.5/512^2 instead of the reference's 161 MB.
 
-    __slots__ = ("q", "k", "heads", "scale", "R")
+    Tensor duck type: code written against the reference's store -- the reference's OWN `optimize.collect_maps`
+    (optimize.py:52-75: `data.reshape(...)`, `data[:, :, :, indices]`, `.permute`, `F.interpolate`, `torch.stack`),
+    reached from its `keypoint_regressor.find_best_indices` / `eval.run_image_with_context_augmented` through its
+    `ptp_utils.run_and_find_attn` -- sees the reference tensor: any tensor attribute, index or torch function applied to
+    a handle materialises `(B*h, R^2, T)` once (cached, no autograd) and forwards to it.  The fused `collect_maps` of
+    this package never does that."""
+
+    __slots__ = ("q", "k", "heads", "scale", "R", "_mat")
 
     def __init__(self, q, k, heads, scale, R):
         self.q, self.k, self.heads, self.scale, self.R = q, k, int(heads), float(scale), int(R)
+        self._mat = None
 
     @property
     def shape(self):
-        return (self.q.shape[0] * self.heads, self.R * self.R, self.k.shape[1])
+        return torch.Size((self.q.shape[0] * self.heads, self.R * self.R, self.k.shape[1]))
+
+    @property
+    def device(self):
+        return self.q.device
+
+    @property
+    def dtype(self):
+        return self.q.dtype
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 3
 
     def materialize(self) -> torch.Tensor:
-        """The reference's stored tensor, (B*h, R^2, T) (no autograd; compat/testing)."""
-        return ops.materialize_probs(self.q.detach(), self.k.detach(), self.heads, self.scale, self.R)
+        """The reference's stored tensor, (B*h, R^2, T) (no autograd; compat/testing).  GPU tensors: the fused map kernel
+        run per head (ops.materialize_probs); host tensors (the module tree on CPU, which is what the build container and
+        oracle/ can drive): the same quantity in torch ops -- softmax_t(bicubic_R(scale q k^T))."""
+        if self._mat is None:
+            q, k = self.q.detach(), self.k.detach()
+            if q.is_cuda:
+                self._mat = ops.materialize_probs(q, k, self.heads, self.scale, self.R)
+            else:
+                self._mat = _materialize_host(q, k, self.heads, self.scale, self.R)
+        return self._mat
+
+    # ---- tensor duck typing (see the class docstring) ----
+    def __getattr__(self, name):
+        if name.startswith("__") or name in FusedAttn.__slots__:
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def conv(a):
+            if isinstance(a, FusedAttn):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(conv(v) for v in a)
+            return a
+        return func(*conv(args), **{k_: conv(v) for k_, v in (kwargs or {}).items()})
+
+
+def _materialize_host(q, k, heads, scale, R):
+    """(B*h, R^2, T) on host tensors: logits at the layer's resolution, bicubic to R (align_corners=False, the resize of
+    ptp_utils.py:520-524 moved behind the bias-free, linear `to_q`), softmax over the tokens."""
+    B, s2, C = q.shape
+    Bk, T, _ = k.shape
+    s, d = int(round(s2 ** 0.5)), C // heads
+    qh = q.reshape(B, s2, heads, d).permute(0, 2, 1, 3)
+    kh = k.expand(B, T, C).reshape(B, T, heads, d).permute(0, 2, 3, 1)
+    S = torch.matmul(qh, kh) * scale                                             # [B,h,s2,T]
+    S = S.permute(0, 1, 3, 2).reshape(B * heads, T, s, s)
+    if s != R:
+        S = F.interpolate(S, size=(R, R), mode="bicubic", align_corners=False)
+    return S.reshape(B * heads, T, R * R).permute(0, 2, 1).softmax(dim=-1).contiguous()
 
 
 def fused_maps(records: List[FusedAttn]) -> torch.Tensor:
