@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the best of a short sweep over {32,64,128}")
     ap.add_argument("--emulated-f32", action="store_true",
                     help="EXPERIMENT (separate line, never the bench of record): frozen nn.Linear GEMMs on the bf16 matrix "
-                         "cores with three-term operand splits (csrc/skp_gemm_x3.hip)")
+                         "cores with three-term operand splits (tools/csrc/skp_gemm_x3.hip)")
     ap.add_argument("--cache-latents", action="store_true",
                     help="EXPERIMENT (separate line, never the bench of record): latents of the un-warped views kept per dataset image "
                          "(optimize.py cache_latents); the 16-image synthetic set then skips half the VAE work on every timed step")

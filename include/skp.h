@@ -104,6 +104,9 @@ int skp_attn_map_bwd_f32(const float* const* S /*[host]*/, float* const* dS /*[h
  * [B,n_rows,R,R] (optimize.py:58-59 keeps `indices` of the T maps); NULL: M is [B,T,R,R].  Requires R % 32 == 0. */
 int skp_attn_map_fwd_wide_f32(const float* const* S /*[host]*/, const int* s /*[host]*/, int L, int B, int H, int T,
                               int R, float* M, float* lse, const int* tokrow, int n_rows, int ldt, void* stream);
+/* 1 when the wide kernel takes these sizes (side <= 64, R % 32 == 0, R*(R/32) <= 65535 tiles, the LDS plan fits), else 0:
+ * the host-side gate callers use to choose between it and the two-pass token-group route (host logic, no launch). */
+int skp_attn_map_fwd_wide_ok(const int* s /*[host]*/, int L, int T, int R);
 
 /* Backward of the fused map for a SPARSE map gradient: the losses of optimize.py:157-206 index the map with the K
  * selected tokens (optimize.py:395-414), so dM is non-zero on K rows per batch row only.
@@ -284,20 +287,6 @@ int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, 
  * Limits: Cin <= 4, W even, B <= 65535, else SKP_E_RANGE. */
 int skp_conv3x3_small_f32(const void* x, const void* w, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
                           void* stream);
-
-/* EXPERIMENT, not the path of record (bench line dtype "f32-emulated (bf16x3)"): fp32 GEMM of the frozen nn.Linear layers on
- * the bf16 matrix cores, every fp32 operand split into three bf16 terms (h + m + l, round to nearest), six products accumulated
- * in fp32 (csrc/skp_gemm_x3.hip).
- *   skp_gemm_x3_split_f32: planes [3][rows][cols] bf16 of w (transpose = 0: w is [rows, cols]; 1: w is [cols, rows]);
- *   skp_gemm_x3_nt_f32:    C[M,N] = A[M,K] . B[N,K]^T (+ bias[N], may be NULL), A fp32 row-major (lda), B = planes [3][N][K],
- *                          C fp32 (ldc).  K % 32 == 0, lda % 4 == 0, A and planes 16-byte aligned, else SKP_E_RANGE. */
-int skp_gemm_x3_split_f32(const void* w, void* planes, int rows, int cols, int transpose, void* stream);
-int skp_gemm_x3_nt_f32(const void* a, const void* b_planes, const void* bias, void* c, int M, int N, int K, int64_t lda,
-                       int64_t ldc, void* stream);
-
-/* Measurement aid (bench.py): sustained rate, in TFLOP/s, of back-to-back independent v_mfma_f32_16x16x4_f32 with
- * `waves_per_simd` (1..4) resident waves on every SIMD.  Synchronises `stream`.  scratch: >= 256*4*256 floats. */
-int skp_probe_mfma_f32(int waves_per_simd, int iters, float* scratch, float* tflops, void* stream);
 
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0

@@ -114,6 +114,9 @@ def collect_maps(controller, from_where=["up_cross"], upsample_res=512, layers=[
         raise RuntimeError("collect_maps: no stored attention layer matches `layers`")
     if all(isinstance(r, FusedAttn) for r in chosen):
         if indices is not None and not torch.is_grad_enabled():  # inference: only the asked-for rows are computed / written
+            for r in chosen:
+                if r.R != chosen[0].R or r.heads != chosen[0].heads:
+                    raise RuntimeError("hooked layers disagree on feature_upsample_res / head count")
             m = ops.attn_map_rows([r.q for r in chosen], [r.k for r in chosen], chosen[0].heads,
                                   [r.scale for r in chosen], chosen[0].R, indices).mean(dim=0)
         else:
@@ -148,10 +151,18 @@ def collect_maps_batched(controller, layers=(0, 1, 2, 3), indices=None) -> torch
     """[B,T,R,R]: one reduced map per batch row (the batched engine's variant); resets the controller.
     `indices` (inference, no autograd): only those tokens' maps, [B,len(indices),R,R]."""
     chosen = [rec for i, rec in enumerate(controller.step_store["attn"]) if i in layers]
+    if not chosen:
+        raise RuntimeError("collect_maps_batched: no stored attention layer matches `layers`")
     if indices is None:
         out = fused_maps(chosen)
+    elif torch.is_grad_enabled() and any(r.q.requires_grad or r.k.requires_grad for r in chosen):
+        # the row-selecting kernel path is inference only (it detaches q / k): with autograd on, gather differentiably
+        out = fused_maps(chosen)[:, torch.as_tensor(indices, device=chosen[0].q.device).long()]
     else:
         R, heads = chosen[0].R, chosen[0].heads
+        for r in chosen:
+            if r.R != R or r.heads != heads:
+                raise RuntimeError("hooked layers disagree on feature_upsample_res / head count")
         out = ops.attn_map_rows([r.q for r in chosen], [r.k for r in chosen], heads, [r.scale for r in chosen], R, indices)
     controller.reset()
     return out

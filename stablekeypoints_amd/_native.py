@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -35,6 +35,7 @@ SIGNATURES = {
     "skp_conv3x3_f4_gn_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_unwarp_accumulate_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "skp_attn_map_fwd_wide_f32": [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "skp_attn_map_fwd_wide_ok": [C.POINTER(_i), _i, _i, _i],
     "skp_attn_map_bwd_sparse_workspace": [C.POINTER(_i), _i, _i, _i, _i, _i, _i],
     "skp_attn_map_bwd_sparse_f32": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp,
                                     _i, _vp],
@@ -60,9 +61,6 @@ SIGNATURES = {
     "skp_conv3x3_s2_filter_f32": [_vp, _vp, _i, _i, _vp],
     "skp_conv3x3_s2_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_small_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "skp_probe_mfma_f32": [_i, _i, _vp, _vp, _vp],
-    "skp_gemm_x3_split_f32": [_vp, _vp, _i, _i, _i, _vp],
-    "skp_gemm_x3_nt_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp],
     "skp_conv3x3_f4_stats_blocks": [_i, _i, _i, _i, _i],
     "skp_conv3x3_f4_stats_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_s2_stats_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -110,6 +108,31 @@ def lib():
         raise NativeLibraryError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
     _lib = l
     return l
+
+
+# measurement aids / experiments live in their own library (tools/csrc -> libskp_lab.so, tools/csrc/skp_lab.h); the product
+# library does not contain them
+LAB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "csrc", "libskp_lab.so")
+LAB_SIGNATURES = {
+    "skp_probe_mfma_f32": [_i, _i, _vp, _vp, _vp],
+    "skp_gemm_x3_split_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "skp_gemm_x3_nt_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp],
+}
+_lab = None
+
+
+def lab():
+    """The measurement / experiment library (bench.py's issue-rate probe, the split-bf16 GEMM experiment)."""
+    global _lab
+    if _lab is None:
+        if not os.path.exists(LAB_PATH):
+            raise NativeLibraryError(f"{LAB_PATH} is missing: `make -C tools/csrc` (measurement aids, not the product library)")
+        l = C.CDLL(LAB_PATH)
+        for name, argtypes in LAB_SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes, fn.restype = argtypes, C.c_int
+        _lab = l
+    return _lab
 
 
 def check(rc: int, what: str):

@@ -176,21 +176,18 @@ void skp_attn_map_fwd_wide_kernel(WideArgs a, float* __restrict__ M,
     }
 }
 
-extern "C" int skp_attn_map_fwd_wide_f32(const float* const* S, const int* s, int L, int B, int H, int T, int R,
-                                         float* M, float* lse, const int* tokrow, int n_rows, int ldt, void* stream) {
-    if (!S || !s || !M || !lse || L <= 0 || B <= 0 || H <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
+// Launch plan of the wide kernel; 0 or the SKP_E_* code the entry point would return for these sizes (host logic only).
+struct WidePlan { int sw, px, threads; long tiles; size_t lds; };
+static int wide_plan(const int* s, int L, int T, int R, WideArgs& a, WidePlan& p) {
+    if (L <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
     if (L > SKP_MAX_LAYERS || T > 1024 || R > 4096 || (R % 32)) return SKP_E_RANGE;
-    const int nt16 = ((T + 15) / 16) * 16;
-    if (ldt < nt16 || (ldt & 3) || (tokrow && n_rows <= 0)) return SKP_E_BADARG;
-    WideArgs a{};
     int smax = 0;
     for (int l = 0; l < L; ++l) {
-        if (!S[l] || s[l] <= 0) return SKP_E_BADARG;
+        if (s[l] <= 0) return SKP_E_BADARG;
         if (s[l] > 64) return SKP_E_RANGE;
-        a.S[l] = S[l]; a.s[l] = s[l];
+        a.s[l] = s[l];
         smax = s[l] > smax ? s[l] : smax;
     }
-    a.L = L; a.B = B; a.H = H; a.T = T; a.R = R; a.ldt = ldt;
     // 64-token slices measured faster than 32 (1.84 vs 2.58 ms at T = 500); 32 only where 64 would leave most lanes idle
     int sw = T <= 192 ? 32 : 64;
     { const char* e = getenv("SKP_MAP_SLICE"); if (e && atoi(e) == 64) sw = 64; if (e && atoi(e) == 32) sw = 32; }
@@ -201,13 +198,42 @@ extern "C" int skp_attn_map_fwd_wide_f32(const float* const* S, const int* s, in
     a.ncmax = (int)(((long)px * smax + R - 1) / R) + 4;
     if (a.ncmax > smax) a.ncmax = smax;
     a.vt_stride = sw * a.NS + 4;
+    p.sw = sw; p.px = px;
+    p.threads = ((px * a.NS + 63) / 64) * 64;
+    p.tiles = (long)R * (R / px);
+    if (p.tiles > 65535 || p.threads > 512) return SKP_E_RANGE;
+    p.lds = ((size_t)a.ncmax * a.vt_stride + 2 * (size_t)a.NS * px * 2) * sizeof(float);
+    if (p.lds > 160 * 1024) return SKP_E_LDS;
+    return 0;
+}
+
+// 1 when skp_attn_map_fwd_wide_f32 takes these sizes (callers fall back to the two-pass token-group route otherwise).
+extern "C" int skp_attn_map_fwd_wide_ok(const int* s, int L, int T, int R) {
+    if (!s) return 0;
+    WideArgs a{};
+    WidePlan p{};
+    return wide_plan(s, L, T, R, a, p) == 0 ? 1 : 0;
+}
+
+extern "C" int skp_attn_map_fwd_wide_f32(const float* const* S, const int* s, int L, int B, int H, int T, int R,
+                                         float* M, float* lse, const int* tokrow, int n_rows, int ldt, void* stream) {
+    if (!S || !s || !M || !lse || L <= 0 || B <= 0 || H <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
+    const int nt16 = ((T + 15) / 16) * 16;
+    if (L <= SKP_MAX_LAYERS && (ldt < nt16 || (ldt & 3) || (tokrow && n_rows <= 0))) return SKP_E_BADARG;
+    WideArgs a{};
+    WidePlan p{};
+    const int rc = wide_plan(s, L, T, R, a, p);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) {
+        if (!S[l]) return SKP_E_BADARG;
+        a.S[l] = S[l];
+    }
+    a.L = L; a.B = B; a.H = H; a.T = T; a.R = R; a.ldt = ldt;
     a.inv_lh = 1.0f / (float)(L * H);
     a.m_bstride = (long)(tokrow ? n_rows : T) * R * R;
-    const int threads = ((px * a.NS + 63) / 64) * 64;
-    const long tiles = (long)R * (R / px);
-    if (tiles > 65535 || threads > 512) return SKP_E_RANGE;
-    const size_t lds = ((size_t)a.ncmax * a.vt_stride + 2 * (size_t)a.NS * px * 2) * sizeof(float);
-    if (lds > 160 * 1024) return SKP_E_LDS;
+    const int sw = p.sw, px = p.px, threads = p.threads;
+    const long tiles = p.tiles;
+    const size_t lds = p.lds;
 #define SKP_WIDE_LAUNCH(SWV, PXV)                                                                              \
     {                                                                                                          \
         if (lds > 64 * 1024) {                                                                                 \

@@ -75,8 +75,6 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
     `thetas` [n,2,3] / `noise` [n,4,h,w] inject the draws for ALL n views (parity tests)."""
     import numpy as np
     from . import dist as skp_dist
-    from . import ptp_utils
-    from ._maps import collect_maps_batched
     from .invertable_transform import RandomAffineWithInverse
     if visualize:
         raise NotImplementedError("plotting is out of scope (SURVEY.md 2.1 row 14)")
@@ -103,18 +101,64 @@ def run_image_with_context_augmented(ldm, image, context, indices, device="cuda"
         skp_dist.broadcast_(noise, 0)
         r = skp_dist.rank()
         thetas, noise = thetas[r::world].cpu(), noise[r::world]
-    views = tr(image[None].repeat(thetas.shape[0], 1, 1, 1), theta=thetas)
+    tot, num = _augmented_group(ldm, image[None], context, indices, controller, dev, layers, noise_level, tr, thetas, noise,
+                                upscale_size, finish=(world == 1))
+    if world == 1:
+        return tot[0]
+    return finish_augmented(tot[0], num[0][None].expand_as(tot[0]).contiguous(), reduce=True)
+
+
+def _augmented_group(ldm, images, context, indices, controller, dev, layers, noise_level, tr, thetas, noise, upscale_size,
+                     finish=True):
+    """`images` [m,3,H,W], `thetas` [m*n,2,3] / `noise` [m*n,4,h,w] (image-major: the n views of image 0, then image 1 ...)
+    -> (sum or sum/count [m,K,S,S], count [m,S,S]).  All m*n views are ONE network batch; per image one fused
+    resize + un-warp + accumulate launch."""
+    from . import ptp_utils
+    from ._maps import collect_maps_batched
+    from .invertable_transform import RandomAffineWithInverse
+    m = images.shape[0]
+    n = thetas.shape[0] // m
+    views = tr(images.repeat_interleave(n, dim=0), theta=thetas)
     ptp_utils.find_pred_noise(ldm, views, context.to(dev), noise_level=noise_level, device=dev, noise=noise,
                               early_exit=True, controllers={dev: controller})
     idx = torch.as_tensor(indices, device=dev).long()
-    maps = collect_maps_batched(controller, layers=layers, indices=idx)    # [n,K,R,R]: only the selected tokens' maps
+    maps = collect_maps_batched(controller, layers=layers, indices=idx)    # [m*n,K,R,R]: only the selected tokens' maps
     # resize R -> upscale_size, un-warp the maps and a ones mask, sum over the views: ONE kernel (the reference's four
     # [n,K,S,S] intermediates are never materialised); a single rank gets sum / count straight from it
     theta_inv = RandomAffineWithInverse.invert(thetas.to(torch.float32))
-    tot, num = ops.unwarp_accumulate(maps, theta_inv, int(upscale_size), finish=(world == 1))
-    if world == 1:
-        return tot
-    return finish_augmented(tot, num[None].expand_as(tot).contiguous(), reduce=True)
+    tots, nums = [], []
+    for i in range(m):
+        tot, num = ops.unwarp_accumulate(maps[i * n:(i + 1) * n], theta_inv[i * n:(i + 1) * n], int(upscale_size), finish=finish)
+        tots.append(tot)
+        nums.append(num)
+    return torch.stack(tots), torch.stack(nums)
+
+
+@torch.no_grad()
+def run_images_with_context_augmented(ldm, images, context, indices, controllers=None, layers=[0, 1, 2, 3, 4, 5],
+                                      augmentation_iterations=20, noise_level=-1, augment_degrees=30,
+                                      augment_scale=(0.9, 1.1), augment_translate=(0.1, 0.1), num_gpus=1, upscale_size=512,
+                                      thetas=None, noise=None):
+    """`run_image_with_context_augmented` for SEVERAL images in one network batch (the dataset loops of
+    keypoint_regressor.py:160-196 / eval.py:424-446 call it once per image): images [m,3,H,W] -> [m,K,S,S].  Per image the
+    result is what the single-image function returns for the same draws (`thetas` [m*n,2,3], `noise` [m*n,4,h,w],
+    image-major)."""
+    from .invertable_transform import RandomAffineWithInverse
+    dev, controller = next(iter(controllers.items()))
+    images = images.to(device=dev, dtype=torch.float32)
+    m = images.shape[0]
+    n = (augmentation_iterations // num_gpus) * num_gpus
+    if n < 1:
+        raise ValueError(f"augmentation_iterations ({augmentation_iterations}) is smaller than num_gpus ({num_gpus})")
+    tr = RandomAffineWithInverse(degrees=augment_degrees, scale=augment_scale, translate=augment_translate)
+    if thetas is None:
+        thetas = tr.sample_theta(m * n)
+    thetas = torch.as_tensor(thetas, dtype=torch.float32)
+    if noise is None:
+        noise = torch.randn(m * n, 4, images.shape[-2] // 8, images.shape[-1] // 8, device=dev)
+    tot, _ = _augmented_group(ldm, images, context, indices, controller, dev, layers, noise_level, tr, thetas, noise.to(dev),
+                              upscale_size, finish=True)
+    return tot
 
 
 def finish_augmented(tot, num, reduce=True):

@@ -36,7 +36,7 @@ def _resnet_forward(m: ResnetBlock2D):
         if m.conv_shortcut is not None:
             # 1x1 shortcut = one batched GEMM on the NCHW planes (no layout transposes); its bias joins conv2's
             res, bias = ops.conv1x1_nobias(x, m.conv_shortcut.weight), _summed_bias(m)
-        if ops.conv3x3_gn_fold_ok(h, m.norm2, m.conv2.weight):
+        if ops.conv3x3_gn_fold_ok(h, m.norm2, m.conv2.weight, off, bias, res):
             return ops.conv3x3_gn_silu(h, m.norm2, m.conv2.weight, off=off, bias=bias, residual=res, want_stats=True)
         h = ops.group_norm_silu(h, m.norm2, off=off)
         # bias + shortcut in the conv epilogue; its block sums serve the next block's first norm

@@ -67,8 +67,13 @@ MAP_WIDE = os.environ.get("SKP_MAP_WIDE", "1") != "0"          # A/B switch: "0"
 MAP_WIDE_MAX_T = 1024
 
 
-def map_wide_supported(T: int, R: int) -> bool:
-    return MAP_WIDE and TOKEN_GROUP < T <= MAP_WIDE_MAX_T and R % 32 == 0
+def map_wide_supported(T: int, R: int, sides: Sequence[int] = (16,)) -> bool:
+    """The one-pass wide kernel serves T in (128, 1024] where its launch plan fits (the library's own gate: layer side
+    <= 64, R % 32 == 0, tile count, LDS); everything else takes the two-pass token-group route."""
+    if not (MAP_WIDE and TOKEN_GROUP < T <= MAP_WIDE_MAX_T and R % 32 == 0):
+        return False
+    si, _keep = N.int_array([int(v) for v in sides])
+    return bool(N.lib().skp_attn_map_fwd_wide_ok(si, len(sides), int(T), int(R)))
 
 
 def _map_fwd(S: Sequence[torch.Tensor], sides: Sequence[int], B: int, H: int, T: int, R: int, tokrow=None, n_rows: int = 0):
@@ -81,7 +86,7 @@ def _map_fwd(S: Sequence[torch.Tensor], sides: Sequence[int], B: int, H: int, T:
     L, ldt = len(S), S[0].shape[-1]
     si, _k2 = N.int_array(sides)
     lib, st = N.lib(), _stream()
-    if map_wide_supported(T, R):
+    if map_wide_supported(T, R, sides):
         M = torch.empty(B, n_rows if tokrow is not None else T, R, R, device=dev, dtype=torch.float32)
         lse = torch.empty(B, L * H, R * R, device=dev, dtype=torch.float32)
         sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
@@ -260,9 +265,11 @@ def attn_map_rows(qs: Sequence[torch.Tensor], ks: Sequence[torch.Tensor], heads:
     T = ks[0].shape[1]
     idx = torch.as_tensor(indices, device=qs[0].device).long().reshape(-1)
     sides = [int(round(q.shape[1] ** 0.5)) for q in qs]
+    if any(s_ * s_ != q.shape[1] or q.shape[0] != qs[0].shape[0] or k.shape[1] != T for s_, q, k in zip(sides, qs, ks)):
+        raise RuntimeError("attn_map_rows: hooked layers disagree on batch rows / token count, or a query length is not a square")
     S = [qk_logits(q.detach(), k.detach(), heads, sc) for q, k, sc in zip(qs, ks, scales)]
     B = qs[0].shape[0]
-    if map_wide_supported(T, R):
+    if map_wide_supported(T, R, sides):
         uniq, inv = torch.unique(idx, return_inverse=True)      # a token asked for twice is written once
         tokrow = torch.full((T,), -1, device=idx.device, dtype=torch.int32)
         tokrow[uniq] = torch.arange(uniq.numel(), device=idx.device, dtype=torch.int32)
@@ -397,7 +404,14 @@ class MapLossesFn(torch.autograd.Function):
         R, H, scales = int(meta["R"]), int(meta["heads"]), tuple(float(v) for v in meta["scales"])
         B, T = qs[0].shape[0], ks[0].shape[1]
         n = B // 2
-        sides = [int(round(q.shape[1] ** 0.5)) for q in qs]
+        if B != 2 * n or len(scales) != L or len(meta["thetas"]) != n:
+            raise RuntimeError("MapLossesFn: rows must be n images followed by their n affine copies, one scale per layer")
+        sides = []
+        for q, k in zip(qs, ks):
+            s_ = int(round(q.shape[1] ** 0.5))
+            if s_ * s_ != q.shape[1] or q.shape[0] != B or k.shape[1] != T or q.shape[2] % H or k.shape[2] != q.shape[2]:
+                raise RuntimeError("MapLossesFn: hooked layers disagree on batch rows / token count / head split")
+            sides.append(s_)
         S = [qk_logits(q, k, H, sc) for q, k, sc in zip(qs, ks, scales)]
         M, lse = _map_fwd(S, sides, B, H, T, R)
         sigma, ns = float(meta["sigma"]), int(meta["num_subjects"])
@@ -413,8 +427,8 @@ class MapLossesFn(torch.autograd.Function):
         for i in range(n):
             am, score = meta["score_fn"](M[i], meta["strategy"], ns, sigma)
             am_t, _ = token_stats(M[n + i], num_subjects=1, sigma=sigma, want_kl=False)
-            N.check(lib.skp_select_tokens(score.data_ptr(), am_t.data_ptr(), T, R, n_cand, K, torch.empty(
-                n_cand, device=dev, dtype=torch.int64).data_ptr(), sel_all[i].data_ptr(), st), "skp_select_tokens")
+            _, sel_i = select_tokens(score, am_t[0], R, n_cand, K)
+            sel_all[i].copy_(sel_i)
             th, _keep = N.float_array(invert_affine(meta["thetas"][i]))
             N.check(lib.skp_losses_fwd_f32(M[i].data_ptr(), M[n + i].data_ptr(), sel_all[i].data_ptr(), K, T, R,
                                            am.data_ptr(), ns, sigma, th, partial[i].data_ptr(), g_sharp[i].data_ptr(),
@@ -907,8 +921,14 @@ def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
 GN_FOLD = os.environ.get("SKP_GN_FOLD", "1") != "0"
 
 
-def conv3x3_gn_fold_ok(x, norm: torch.nn.GroupNorm, weight) -> bool:
-    if not (GN_FOLD and x.is_cuda and x.dtype == torch.float32) or (torch.is_grad_enabled() and x.requires_grad):
+def conv3x3_gn_fold_ok(x, norm: torch.nn.GroupNorm, weight, *others) -> bool:
+    """`others`: every further tensor the folded call will read (offset, bias, residual).  The folded kernel is forward
+    only: with autograd on, ANY operand that requires a gradient (input, norm affine, weight, offset, bias, residual) sends
+    the block down the differentiable route."""
+    if not (GN_FOLD and x.is_cuda and x.dtype == torch.float32):
+        return False
+    if torch.is_grad_enabled() and any(t_ is not None and t_.requires_grad
+                                       for t_ in (x, weight, norm.weight, norm.bias, *others)):
         return False
     if weight.requires_grad or not conv3x3_f4_ok(x.shape, weight.shape) or not group_norm_supported(x, norm.num_groups):
         return False
@@ -928,6 +948,10 @@ def conv3x3_gn_silu(x, norm: torch.nn.GroupNorm, weight, off=None, bias=None, re
     B, C, H, W = x.shape
     G, cout = norm.num_groups, int(weight.shape[0])
     off_c = _dev(off.reshape(B, C), "off") if off is not None else None
+    bias = _dev(bias, "bias") if bias is not None else None
+    residual = _dev(residual, "residual") if residual is not None else None
+    if residual is not None and tuple(residual.shape) != (B, cout, H, W):
+        raise RuntimeError("conv3x3_gn_silu: residual must have the output's shape")
     mean = torch.empty(B, G, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     coef = torch.empty(B, C, 2, device=x.device, dtype=torch.float32)
@@ -981,14 +1005,14 @@ def mfma_issue_rate(waves_per_simd: int = 1, iters: int = 20000, device=None) ->
     scratch = torch.empty(256 * 4 * 256, device=dev, dtype=torch.float32)
     out = ctypes.c_float(0.0)
     with torch.cuda.device(dev):
-        N.check(N.lib().skp_probe_mfma_f32(int(waves_per_simd), int(iters), scratch.data_ptr(), ctypes.addressof(out), _stream()),
+        N.check(N.lab().skp_probe_mfma_f32(int(waves_per_simd), int(iters), scratch.data_ptr(), ctypes.addressof(out), _stream()),
                 "skp_probe_mfma_f32")
     return float(out.value)
 
 
 # ---------------------------------------------------------------------------------------------------------
 # EXPERIMENT (SKP_EMULATED_F32=1, separate bench line): frozen nn.Linear layers on the bf16 matrix cores with three-term
-# operand splits and six fp32-accumulated products (csrc/skp_gemm_x3.hip).  Off by default: fp32 MFMA / library GEMMs.
+# operand splits and six fp32-accumulated products (tools/csrc/skp_gemm_x3.hip).  Off by default: fp32 MFMA / library GEMMs.
 # ---------------------------------------------------------------------------------------------------------
 EMULATED_F32 = os.environ.get("SKP_EMULATED_F32", "0") == "1"
 
@@ -1010,7 +1034,7 @@ def _x3_planes(weight, transpose: bool):
     n, k = w.shape
     rows, cols = (k, n) if transpose else (n, k)
     planes = torch.empty(3 * rows * cols, device=w.device, dtype=torch.bfloat16)
-    N.check(N.lib().skp_gemm_x3_split_f32(w.data_ptr(), planes.data_ptr(), rows, cols, int(transpose), _stream()),
+    N.check(N.lab().skp_gemm_x3_split_f32(w.data_ptr(), planes.data_ptr(), rows, cols, int(transpose), _stream()),
             "skp_gemm_x3_split_f32")
     _X3_CACHE[key] = (weight._version, planes, weakref.ref(owner))
     return planes
@@ -1041,7 +1065,7 @@ class LinearX3Fn(torch.autograd.Function):
         m, n = x2.shape[0], weight.shape[0]
         y = torch.empty(m, n, device=x.device, dtype=torch.float32)
         bb = _dev(bias.detach(), "bias") if bias is not None else None
-        N.check(N.lib().skp_gemm_x3_nt_f32(x2.data_ptr(), _x3_planes(weight, False).data_ptr(),
+        N.check(N.lab().skp_gemm_x3_nt_f32(x2.data_ptr(), _x3_planes(weight, False).data_ptr(),
                                            bb.data_ptr() if bb is not None else None, y.data_ptr(), m, n, k, k, n, _stream()),
                 "skp_gemm_x3_nt_f32")
         ctx.weight = weight
@@ -1057,7 +1081,7 @@ class LinearX3Fn(torch.autograd.Function):
         d2 = _dev(dy.reshape(-1, n), "dy")
         m = d2.shape[0]
         dx = torch.empty(m, k, device=dy.device, dtype=torch.float32)
-        N.check(N.lib().skp_gemm_x3_nt_f32(d2.data_ptr(), _x3_planes(w, True).data_ptr(), None, dx.data_ptr(), m, k, n, n, k,
+        N.check(N.lab().skp_gemm_x3_nt_f32(d2.data_ptr(), _x3_planes(w, True).data_ptr(), None, dx.data_ptr(), m, k, n, n, k,
                                            _stream()), "skp_gemm_x3_nt_f32")
         return dx.reshape(ctx.xshape), None, None
 

@@ -340,3 +340,127 @@ def test_constant_time_path_is_kept_and_invalidated():
     unet.time_embedding.linear_1.weight.requires_grad_(True)
     e1, e2 = unet.time_path(x, t.repeat(2)), unet.time_path(x, t.repeat(2))
     assert e1 is not e2 and e1.requires_grad
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4
+# ---------------------------------------------------------------------------------------------------------------------
+def test_lab_library_is_separate_and_exports_its_header():
+    """Measurement aids / experiments are NOT in the product library: tools/csrc/libskp_lab.so exports what
+    tools/csrc/skp_lab.h declares, libskp_hip.so exports none of it."""
+    from stablekeypoints_amd import _native as N
+    lab_dir = os.path.join(ROOT, "tools", "csrc")
+    if not os.path.exists(N.LAB_PATH):
+        subprocess.run(["make", "-C", lab_dir, "-j2"], check=True)
+    hdr = open(os.path.join(lab_dir, "skp_lab.h")).read()
+    declared = sorted(set(re.findall(r"^int\s+(skp_\w+)\s*\(", hdr, flags=re.M)))
+    assert declared == sorted(N.LAB_SIGNATURES) and len(declared) == 3
+    lab, lib = N.lab(), N.lib()
+    for name in declared:
+        assert hasattr(lab, name) and not hasattr(lib, name), name
+
+
+def test_fused_attn_handle_is_a_tensor_duck_type():
+    """The reference's own `optimize.collect_maps` op sequence (optimize.py:52-75) on `FusedAttn` handles: reshape, index,
+    permute, interpolate, stack + mean -- equal to the same ops on the materialised (B*h, R^2, T) tensor; the handle
+    materialises once; shape / len / device answer without materialising."""
+    import torch.nn.functional as F
+    from stablekeypoints_amd._maps import FusedAttn, collect_maps
+    from stablekeypoints_amd.ptp_utils import AttentionStore
+    g = torch.Generator().manual_seed(3)
+    recs = [FusedAttn(torch.randn(2, s * s, 32, generator=g), torch.randn(1, 7, 32, generator=g), 4, 0.35, 12) for s in (4, 4, 6)]
+    assert recs[0].shape == (8, 144, 7) and len(recs[0]) == 8 and recs[0]._mat is None and recs[0].device.type == "cpu"
+    idx = torch.tensor([3, 0, 3])
+
+    def reference_order(store):
+        out = []
+        for data in store:
+            data = data.reshape(data.shape[0], int(data.shape[1] ** 0.5), int(data.shape[1] ** 0.5), data.shape[2])
+            data = data[:, :, :, idx].permute(0, 3, 1, 2)
+            out.append(F.interpolate(data, size=(20, 20), mode="bilinear", align_corners=False))
+        return torch.stack(out, dim=0).mean(dim=(0, 1))
+
+    got = reference_order(recs)
+    want = reference_order([r.materialize() for r in recs])
+    assert torch.equal(got, want) and got.shape == (3, 20, 20)
+    first = recs[0]._mat
+    assert first is not None and recs[0].materialize() is first                 # cached
+    torch.testing.assert_close(first.sum(-1), torch.ones(8, 144))               # softmax over the tokens
+    assert torch.equal(torch.stack(recs[:2]), torch.stack([recs[0]._mat, recs[1]._mat]))
+    # the package's own collect_maps on a store of handles that live on the HOST takes the materialised route
+    ctrl = AttentionStore()
+    for r in recs[:2]:
+        ctrl.step_store["attn"].append(r.materialize())
+    m = collect_maps(ctrl, upsample_res=-1, layers=[0, 1])
+    assert m.shape == (7, 12, 12) and len(ctrl.step_store["attn"]) == 0
+
+
+def test_wide_map_gate_mirrors_the_kernel_limits():
+    from stablekeypoints_amd import _native as N, ops
+    lib = N.lib()
+
+    def ok(sides, T, R):
+        si, _k = N.int_array(sides)
+        return lib.skp_attn_map_fwd_wide_ok(si, len(sides), T, R)
+    assert ok([16, 16, 16, 32], 500, 128) == 1 and ok([64], 1000, 512) == 1
+    assert ok([65], 500, 128) == 0                      # layer side beyond the kernel's 64
+    assert ok([16], 500, 100) == 0                      # R % 32
+    assert ok([16], 1025, 128) == 0 and ok([16], 500, 2048) == 0       # token count; R * (R / 32) tiles > 65535
+    assert ops.map_wide_supported(500, 128, [16, 32]) and not ops.map_wide_supported(500, 128, [96])
+    assert not ops.map_wide_supported(77, 128, [16])    # T <= 128 is the narrow kernel's
+
+
+def _kp_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from stablekeypoints_amd import dist as D, keypoint_regressor as KR
+    if world > 1:
+        D.init_from_env("gloo")
+    src, tgt, vis = _run_fake_keypoints(KR)
+    torch.save({"src": src, "tgt": tgt}, os.path.join(out, f"w{world}r{rank}.pt"))
+    if world > 1:
+        D.barrier()
+        dist.destroy_process_group()
+
+
+def _run_fake_keypoints(KR):
+    """precompute_all_keypoints with the network replaced by a deterministic host function of (image, thetas, noise)."""
+    from types import SimpleNamespace
+    n_img, K, n_aug = 7, 3, 2
+
+    def fake_aug(ldm, images, context, indices, controllers=None, thetas=None, noise=None, upscale_size=512, **kw):
+        m = images.shape[0]
+        maps = torch.zeros(m, K, 16, 16)
+        for i in range(m):
+            for k in range(K):
+                v = float(images[i].sum() + thetas[i * n_aug:(i + 1) * n_aug].sum() + noise[i * n_aug:(i + 1) * n_aug].sum()) + k
+                maps[i, k, int(abs(v) * 7) % 16, int(abs(v) * 13) % 16] = 1.0
+        return maps
+
+    KR.run_images_with_context_augmented = fake_aug
+    KR.keypoints_from_maps = lambda mp, strategy="argmax": torch.stack(
+        [mp.flatten(1).argmax(1) // 16, mp.flatten(1).argmax(1) % 16], dim=-1).float() / 16
+    g = torch.Generator().manual_seed(5)
+    data = [{"img": torch.rand(3, 8, 8, generator=g), "kpts": torch.rand(4, 2, generator=g)} for _ in range(n_img)]
+    args = SimpleNamespace(max_num_points=6, augmentation_iterations=n_aug, layers=[0], noise_level=-1, augment_degrees=1,
+                           augment_scale=[1, 1], augment_translate=[0, 0], max_loc_strategy="argmax", images_per_forward=2)
+    draws = (torch.randperm(n_img, generator=g).tolist(), torch.rand(n_img * n_aug, 4, 1, 1, generator=g),
+             torch.rand(n_img * n_aug, 2, 3, generator=g))
+    return KR.precompute_all_keypoints(None, torch.zeros(1, 4, 8), torch.arange(K), args, {torch.device("cpu"): None}, 1,
+                                       dataset=data, draws=draws)
+
+
+def test_precompute_all_keypoints_rank_sharding_gloo(tmp_path):
+    """Dataset-level keypoint driver, host logic: positions of the shuffled order are dealt `p % world`, locations are
+    all-gathered back into loader order (uneven split: 6 images over 2 ranks x groups of 2 ... and `max_num_points` cuts
+    the pass short), targets follow the same order -- two gloo ranks == one process."""
+    import torch.multiprocessing as mp
+    _kp_worker(0, 1, 0, str(tmp_path))
+    one = torch.load(tmp_path / "w1r0.pt")
+    assert one["src"].shape == (6, 3, 2) and one["tgt"].shape == (6, 4, 2)
+    mp.spawn(_kp_worker, args=(2, 29300 + os.getpid() % 200, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "w2r0.pt"), torch.load(tmp_path / "w2r1.pt")
+    for key in ("src", "tgt"):
+        assert torch.equal(a[key], b[key]) and torch.equal(a[key], one[key]), key

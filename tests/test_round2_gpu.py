@@ -591,7 +591,7 @@ def test_split_bf16_gemm_is_as_accurate_as_fp32(ops, M, N, K, with_bias):
     y = ops.LinearX3Fn.apply(x, w, b)
     gx = torch.empty_like(x)                                    # input gradient through the same kernel (transposed planes)
     nat = ops.N
-    nat.check(nat.lib().skp_gemm_x3_nt_f32(dy.data_ptr(), ops._x3_planes(w, True).data_ptr(), None, gx.data_ptr(), M, K, N, N, K,
+    nat.check(nat.lab().skp_gemm_x3_nt_f32(dy.data_ptr(), ops._x3_planes(w, True).data_ptr(), None, gx.data_ptr(), M, K, N, N, K,
                                            torch.cuda.current_stream().cuda_stream), "skp_gemm_x3_nt_f32")
     e32, e3 = (y32.double() - ref).abs().max().item(), (y.double() - ref).abs().max().item()
     ge32, ge3 = (g32.double() - gref.double()).abs().max().item(), (gx.double() - gref.double()).abs().max().item()

@@ -15,6 +15,7 @@
 // 80 bytes (the 16-byte operand reads of 16 consecutive rows then touch 64 distinct banks): 60 KB -> two workgroups per CU.
 // The next stage's global loads are in flight under the stage's MFMAs (registers), split + LDS write between two barriers.
 #include "skp_common.h"
+#include "skp_lab.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -4,6 +4,7 @@
 // (profiles/r02_mfma_valu_probe.md: ~0.77 of nominal with one wave per SIMD, ~0.86 with two; fp32 VALU work of the same
 // wave is additive, not hidden).
 #include "skp_common.h"
+#include "skp_lab.h"
 
 namespace {
 __global__ __launch_bounds__(256) void skp_probe_mfma_kernel(float* out, int iters, float a, float b) {

@@ -41,7 +41,7 @@ def main():
         planes = ops._x3_planes(w, False)
         y = torch.empty(M, N, device=x.device)
         st = torch.cuda.current_stream().cuda_stream
-        lib = ops.N.lib()
+        lib = ops.N.lab()
         t3 = timed(lambda: lib.skp_gemm_x3_nt_f32(x.data_ptr(), planes.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, K, N, st),
                    a.iters)                                     # straight through the C-ABI: no per-call Python allocation
         fl = 2.0 * M * N * K
