@@ -55,8 +55,10 @@ def parse():
                     help="weak: --images-per-rank images on every rank (global batch grows with N); strong: the global "
                          "batch is fixed at --global-batch images (BASELINE config 3: 8 images, 1 per rank at N=8)")
     ap.add_argument("--global-batch", type=int, default=8, help="images per optimizer step with --scaling strong")
-    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off", "full"],
-                    help="full: SURVEY 8(d)'s complete protocol (C1 256^2 x 50 steps + 512^2 x 3 steps + thread sweep; minutes)")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "on", "off", "full", "sample"],
+                    help="auto / on / full: SURVEY 8(d)'s complete protocol (thread sweep, C1 = 256^2 x 50 optimizer steps, "
+                         "512^2 x 3 steps; ~6 min of host time); sample: C1 cut to 5 steps (~2 min); off: no CPU leg")
+    ap.add_argument("--conv-log", default="", help="write the per-launch list of conv_step_accounting to this JSON file")
     ap.add_argument("--cpu-image-size", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the best of a short sweep over {32,64,128}")
     ap.add_argument("--emulated-f32", action="store_true",
@@ -175,16 +177,30 @@ def self_attn_roofline(ops, B, iters, device):
 
 
 def conv_roofline(ops, B, image_size, iters, device):
-    """The Winograd F(4x4,3x3) conv kernel at the heaviest launch shape of the step: the VAE encoder's first-level
-    ResnetBlock2D convs (128 -> 128 channels at image resolution, B rows).  Executed MFMA FLOPs = direct-form FLOPs / 4
-    (36 multiplies per 4x4 output tile and channel pair instead of 144); algorithmic bytes = input + output + filter."""
+    """The Winograd F(4x4,3x3) conv kernel at the heaviest launch shape of the step, IN THE FORM THE STEP LAUNCHES IT: the VAE
+    encoder's first-level ResnetBlock2D convs (128 -> 128 channels at image resolution, B rows) run as
+    skp_wino4_conv_c128_kernel<STATS = true, GNF = true> -- GroupNorm + SiLU of the input applied in the patch load, block
+    statistics for the next GroupNorm left behind by the epilogue (launches #0-#3 of a step).  Executed MFMA FLOPs =
+    direct-form FLOPs / 4 (36 multiplies per 4x4 output tile and channel pair instead of 144); algorithmic bytes = input +
+    output + filter.  Where the folded form does not serve the shape (reduced-width test models) the plain form is timed."""
+    lib, N = ops.N.lib(), ops.N
     g = torch.Generator(device="cpu").manual_seed(2)
     ci = co = 128
     B = min(B, max(1, (2 ** 31 - 1) // (ci * image_size * image_size * 4)))   # one launch (the op chunks larger batches)
     x = torch.randn(B, ci, image_size, image_size, generator=g).to(device)
     w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
     U = ops._wino4_filters(w, False)
-    fn = lambda: ops._conv3x3_f4_raw(x, U, None, co)
+    nblk = ops.conv3x3_stats_blocks(x.shape, w.shape)
+    folded = bool(nblk) and bool(lib.skp_conv3x3_f4_gn_ok(B, ci, co, image_size, image_size))
+    if folded:
+        y = torch.empty(B, co, image_size, image_size, device=device)
+        stats = torch.empty(B, co, nblk, 2, device=device)
+        coef = torch.stack([torch.full((B, ci), 0.7), torch.full((B, ci), 0.1)], dim=-1).to(device).contiguous()
+        fn = lambda: N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), None, None, y.data_ptr(), stats.data_ptr(),
+                                                       coef.data_ptr(), B, ci, co, image_size, image_size, ops._stream()),
+                             "skp_conv3x3_f4_gn_f32")
+    else:
+        fn = lambda: ops._conv3x3_f4_raw(x, U, None, co)
     for _ in range(8):                                           # as above: warm clocks before timing
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -197,7 +213,7 @@ def conv_roofline(ops, B, image_size, iters, device):
     nbytes = 4 * (B * ci * image_size ** 2 + B * co * image_size ** 2 + 36 * ci * co)
     units = 8 * ((((B * (image_size // 4) ** 2 + 15) // 16) + 7) // 8) * (co // 128)
     grid_threads = min(units, 256) * 256                         # 128-channel form: persistent, one workgroup per CU
-    return t, direct, nbytes, grid_threads, B
+    return t, direct, nbytes, grid_threads, B, folded
 
 
 def conv_step_forms(ops, B, image_size, iters, device):
@@ -207,8 +223,9 @@ def conv_step_forms(ops, B, image_size, iters, device):
     lib, N = ops.N.lib(), ops.N
     g = torch.Generator(device="cpu").manual_seed(3)
     out = []
-    for (ci, co, sz, form) in ((128, 128, image_size, "gn_fold+stats"), (256, 256, image_size // 2, "stats"),
-                               (512, 512, image_size // 4, "stats"), (320, 320, image_size // 8, "stats")):
+    for (ci, co, sz, form) in ((128, 128, image_size, "plain"), (128, 128, image_size, "gn_fold+stats"),
+                               (256, 256, image_size // 2, "stats"), (512, 512, image_size // 4, "stats"),
+                               (320, 320, image_size // 8, "stats")):
         rows = min(B, max(1, (2 ** 31 - 1) // (max(ci, co) * sz * sz * 4)))
         x = torch.randn(rows, ci, sz, sz, generator=g).to(device)
         w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
@@ -224,6 +241,8 @@ def conv_step_forms(ops, B, image_size, iters, device):
             coef = torch.stack([torch.full((rows, ci), 0.7), torch.full((rows, ci), 0.1)], dim=-1).to(device).contiguous()
             fn = lambda: N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), None, None, y.data_ptr(), stats.data_ptr(),
                                                            coef.data_ptr(), rows, ci, co, sz, sz, ops._stream()), "skp_conv3x3_f4_gn_f32")
+        elif form == "plain":                                     # rounds 1-3 headline form: no statistics, no folded norm
+            fn = lambda: ops._conv3x3_f4_raw(x, U, None, co, out=y)
         else:
             fn = lambda: ops._conv3x3_f4_raw(x, U, None, co, out=y, stats=stats)
         for _ in range(6):
@@ -241,12 +260,65 @@ def conv_step_forms(ops, B, image_size, iters, device):
     return out
 
 
+def conv_step_accounting(ops, one_step, log_path=None):
+    """Every Winograd F(4x4,3x3) launch of ONE optimizer step (VAE encoder + UNet forward + UNet backward-data), timed with an
+    event pair on the launch stream around each C-ABI call (the K-split reduction of a split launch included), with its
+    algorithmic FLOPs = 2*9*Cin*Cout*B*H*W / 4: the TIME-WEIGHTED fraction of the fp32 matrix peak over all of them
+    (sum of FLOPs / sum of time / 157.3) is the number the per-shape `roofline.frac` cannot give.  The launch list goes to
+    `log_path` (tools/step_breakdown.py joins it with a rocprofv3 kernel trace by launch order)."""
+    lib = ops.N.lib()
+    names = {"skp_conv3x3_f4_f32": 6, "skp_conv3x3_f4_stats_f32": 6, "skp_conv3x3_f4_gn_f32": 7}     # index of B in the arguments
+    real = {n: getattr(lib, n) for n in names}
+    log = []
+
+    def wrap(name, fn, ib):
+        def call(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            log.append((name, tuple(int(v) for v in args[ib:ib + 5]), e0, e1))
+            return rc
+        return call
+
+    one_step()                                                   # steady state first (wrappers off)
+    try:
+        for n, ib in names.items():
+            setattr(lib, n, wrap(n, real[n], ib))
+        one_step()
+    finally:
+        for n in names:
+            setattr(lib, n, real[n])
+    torch.cuda.synchronize()
+    rows, by_shape = [], {}
+    for name, (B, ci, co, H, W), e0, e1 in log:
+        us = e0.elapsed_time(e1) * 1e3
+        fl = 2.0 * 9 * ci * co * B * H * W / 4
+        rows.append({"entry": name, "B": B, "Cin": ci, "Cout": co, "H": H, "W": W, "algorithmic_flops": fl, "us": us})
+        d = by_shape.setdefault((name.replace("skp_conv3x3_f4_", "").replace("_f32", "") or "plain", ci, co, H, W, B), [0, 0.0, 0.0])
+        d[0] += 1; d[1] += fl; d[2] += us
+    if not rows:
+        return None
+    tf, tus = sum(r["algorithmic_flops"] for r in rows), sum(r["us"] for r in rows)
+    top = sorted(by_shape.items(), key=lambda kv: -kv[1][2])[:12]
+    out = {"what": "all Winograd F(4x4,3x3) launches of one optimizer step (forward + backward-data, K-split reductions "
+                   "included), one event pair per C-ABI call on the launch stream",
+           "launches": len(rows), "algorithmic_flops": tf, "ms": tus / 1e3, "achieved": tf / tus / 1e6, "peak": F32_MATRIX_PEAK_TF,
+           "unit": "TFLOP/s", "frac": tf / tus / 1e6 / F32_MATRIX_PEAK_TF,
+           "heaviest_shapes": [{"entry": k[0], "shape": f"{k[1]}->{k[2]} ch at {k[3]}x{k[4]}, {k[5]} rows", "calls": v[0],
+                                "ms": v[2] / 1e3, "frac": v[1] / v[2] / 1e6 / F32_MATRIX_PEAK_TF} for k, v in top]}
+    if log_path:
+        with open(log_path, "w") as f:
+            json.dump({"launches": rows, "summary": {k: out[k] for k in ("launches", "algorithmic_flops", "ms", "achieved", "frac")}}, f)
+    return out
+
+
 def cpu_baseline(ldm_cpu, args):
     """Oracle reference-order CPU step (oracle/cpu_path.py: materialised attention, x-upsample + second to_q, stack+mean
     collect_maps, python selection, torch losses, Adam) on the host cores -- a BOUNDED sample:
       default: thread sweep {32,64,128} on one 256^2 image each, then at the best count: C1 shape (256^2, batch 1) for
-               5 optimizer steps and the bench shape (512^2) for 1 warm-up + 3 timed steps;
-      --cpu-baseline full: C1 for the full 50 steps.
+               the protocol's full 50 optimizer steps (SURVEY.md 8(d)) and the bench shape (512^2) for 1 warm-up + 3 timed steps;
+      --cpu-baseline sample: C1 cut to 5 steps (labelled `sampled`).
     `value` is the bench-shape rate (same image size as the GPU line); the C1 rate rides along."""
     from oracle import cpu_path
     ncpu = os.cpu_count() or 1
@@ -271,7 +343,7 @@ def cpu_baseline(ldm_cpu, args):
                 if len(sweep) > 1 and sweep[th] < 0.8 * max(sweep.values()):
                     break                                        # past the knee: more threads only oversubscribe
         best = max(sweep, key=sweep.get) if sweep else min(ncpu, 32)
-    c1_steps = 50 if args.cpu_baseline == "full" else 5
+    c1_steps = 5 if args.cpu_baseline == "sample" else 50
     c1_rate, c1_sec = run(256, c1_steps, best)
     size = args.cpu_image_size
     run(size, 1, best)                                           # warm-up at the bench shape
@@ -284,7 +356,7 @@ def cpu_baseline(ldm_cpu, args):
                        "full_protocol_steps": 50,
                        "what": "BASELINE config 1 shape (256^2, 1 image, batch 1), reference op order"
                                + ("" if c1_steps >= 50 else f" -- a {c1_steps}-step SAMPLE of the 50-step protocol "
-                                  "(--cpu-baseline full runs all 50)")},
+                                  "(the default runs all 50)")},
             "thread_sweep_256_images_per_sec": {str(k): v for k, v in sweep.items()}}
 
 
@@ -443,7 +515,7 @@ def main():
 
     t_build = time.time()
     cpu_stats = None
-    want_cpu = a.cpu_baseline in ("on", "full") or (a.cpu_baseline == "auto" and world == 1 and a.model == "sd15")
+    want_cpu = a.cpu_baseline in ("on", "full", "sample") or (a.cpu_baseline == "auto" and world == 1 and a.model == "sd15")
     want_verify = a.verify == "on" or (a.verify == "auto" and want_cpu)
     ldm_cpu = None
     if (want_cpu or want_verify) and rank == 0:
@@ -533,8 +605,16 @@ def main():
         ldims = hooked_layer_dims(a.model, image_size)
         kt, fwd_bytes, bwd_bytes, flops_equiv = map_kernel_roofline(ops, B, a.tokens, a.res, a.kernel_iters, dev, ldims, a.top_k)
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(10, a.kernel_iters // 3), dev)
-        cv_t, cv_direct, cv_bytes, cv_grid, cv_rows = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
+        cv_t, cv_direct, cv_bytes, cv_grid, cv_rows, cv_folded = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         cv_forms = conv_step_forms(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
+        def local_step():                                        # rank 0 only: the step without its collective
+            nonlocal cursor
+            idx = [(cursor + i) % len(data) for i in range(per_rank)]
+            cursor += per_rank
+            group_step(ldm, torch.stack([data[i]["img"] for i in idx]), ctx, args, controller, transform, denom=global_batch,
+                       latent_cache=latent_cache, ids=idx)
+            ctx.grad = None
+        conv_all = conv_step_accounting(ops, local_step, a.conv_log or None)
         ach = fwd_bytes / kt["fwd"] / 1e9
         value = global_batch * a.steps / elapsed
         issue1, issue2 = ops.mfma_issue_rate(1, device=dev), ops.mfma_issue_rate(2, device=dev)
@@ -587,15 +667,20 @@ def main():
                                             "(latents are re-encoded every step: --cache-latents is a separate experiment line)"},
             # dominant kernel of the step by time: the Winograd conv of the frozen blocks, priced on the
             # fp32 matrix-core peak with the FLOPs it actually executes (direct-form FLOPs / 4)
-            "roofline": {"kernel": f"skp_wino4_conv_c128_kernel (Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {min(image_size, 512)}^2, "
-                                   f"{cv_rows} rows: heaviest launch shape of the step, plain form as in rounds 1-2; "
-                                   f"step_forms lists the forms / shapes the step launches)",
+            "roofline": {"kernel": f"skp_wino4_conv_c128_kernel<STATS={'true' if cv_folded else 'false'}, GNF={'true' if cv_folded else 'false'}> "
+                                   f"(Winograd F(4x4,3x3) 3x3 conv, 128->128 ch at {min(image_size, 512)}^2, {cv_rows} rows: heaviest launch "
+                                   "shape of the step IN THE FORM THE STEP LAUNCHES IT -- GroupNorm+SiLU folded into the patch load, block "
+                                   "statistics in the epilogue; step_forms has the plain form of rounds 1-3 and the other shapes, "
+                                   "conv_all_launches the time-weighted fraction over every Winograd launch of a step)",
                          "bound": "mfma", "achieved": cv_direct / 4 / cv_t / 1e12, "peak": F32_MATRIX_PEAK_TF,
                          "unit": "TFLOP/s", "frac": cv_direct / 4 / cv_t / 1e12 / F32_MATRIX_PEAK_TF,
                          "traffic": conv_traffic, "traffic_source": conv_src,
                          "launch_us": cv_t * 1e6, "algorithmic_flops": cv_direct / 4, "algorithmic_bytes": cv_bytes,
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
-                         "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "step_forms": cv_forms},
+                         "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
+                         "peak_note": "frac is against the NOMINAL 157.3 TF/s; mfma_issue_ceiling gives what back-to-back fp32 MFMAs "
+                                      f"retire on this box ({issue1:.1f} TF/s at one wave per SIMD, which is what this kernel holds)",
+                         "step_forms": cv_forms, "conv_all_launches": conv_all},
             # the north-star attention kernel (BASELINE metric: "fraction of the attention roofline")
             "roofline_attn_map": {"kernel": kt["fwd_kernel"] + " (fused up-res softmax map, forward)", "bwd_route": kt["bwd_route"],
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

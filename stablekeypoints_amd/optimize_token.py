@@ -31,7 +31,16 @@ def load_ldm(device, type="CompVis/stable-diffusion-v1-4", feature_upsample_res=
     # patched once: the module tree is never re-replicated (cf. the forward-pre-hook of optimize_token.py:60-69)
     ptp_utils.register_attention_control(ldm.unet, controllers[dev], feature_upsample_res=feature_upsample_res)
     ptp_utils.accelerate_cross_attention(ldm.unet)     # down/mid cross layers: same fused core, never stored
-    if dev.type == "cuda":                              # GroupNorm(+bias/temb offset)+SiLU of the frozen blocks, fused
+    if dev.type == "cuda":
+        # the attention cores have HIP kernels for fixed head sizes and NO eager route on the GPU (ptp_utils._attention_core):
+        # refuse an unsupported UNet configuration here, not in the middle of the first forward
+        from . import ops
+        bad = sorted({m.to_q.weight.shape[0] // m.heads for m in ldm.unet.modules() if m.__class__.__name__ == "CrossAttention"
+                      and not ops.self_attn_supported(m.to_q.weight.shape[0], m.heads)})
+        if bad:
+            raise RuntimeError(f"load_ldm: attention head sizes {bad} have no HIP kernel (built: {ops.CROSS_ATTN_HEAD_DIMS}); "
+                               "see INTEGRATION.md, 'Supported UNet configurations'")
+        # GroupNorm(+bias/temb offset)+SiLU of the frozen blocks, fused
         from .ldm.fused import fuse_norms
         fuse_norms(ldm.unet)
         fuse_norms(ldm.vae)

@@ -177,7 +177,7 @@ def test_bench_two_ranks_one_gpu_gloo():
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--model", "tiny",
            "--image-size", "128", "--res", "32", "--tokens", "16", "--steps", "2", "--warmup", "1", "--cpu-baseline", "off",
            "--kernel-iters", "3"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
     d = json.loads(lines[0])
@@ -187,7 +187,7 @@ def test_bench_two_ranks_one_gpu_gloo():
     assert d["collective_check"]["embedding_identical_on_all_ranks"] is True
     # strong scaling: the global batch stays at --global-batch, each rank takes half
     cmd = cmd[:cmd.index("--master-port") + 1] + [str(29900 + os.getpid() % 90)] + cmd[cmd.index("--master-port") + 2:]
-    out = subprocess.run(cmd + ["--scaling", "strong", "--global-batch", "4"], capture_output=True, text=True, timeout=600,
+    out = subprocess.run(cmd + ["--scaling", "strong", "--global-batch", "4"], capture_output=True, text=True, timeout=300,
                          env=env, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]

@@ -1,9 +1,17 @@
 #!/usr/bin/env python
 """Classify the kernels of a rocprofv3 `--kernel-trace -f csv` run of bench.py into kernel classes, over a
 steady-state window: the last N optimisation steps, delimited by the Adam (multi_tensor_apply) launches.
-usage: step_breakdown.py <run_kernel_trace.csv> [N=2]"""
+usage: step_breakdown.py <run_kernel_trace.csv> [N=2] [conv_log.json]
+
+With the launch list `bench.py --conv-log conv_log.json` wrote (shape + algorithmic FLOPs of every Winograd F(4x4,3x3) call of
+one step, in launch order) the trace's `skp_wino4_conv*` launches are matched to it by position and the TIME-WEIGHTED fraction
+of the fp32 matrix peak over ALL `skp_wino4_*` kernels of a step (K-split reductions included in the time) is printed:
+sum of FLOPs / sum of kernel time / 157.3 TF/s -- the figure bench.py carries as roofline.conv_all_launches.frac."""
 import csv
+import json
 import sys
+
+F32_MATRIX_PEAK_TF = 157.3
 
 CLASSES = [
     ("skp conv3x3 (Winograd stride 1 + direct stride 2)", ("skp_wino", "skp_conv_s2")),
@@ -24,6 +32,7 @@ CLASSES = [
 def main():
     path = sys.argv[1]
     nwin = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    conv_log = json.load(open(sys.argv[3]))["launches"] if len(sys.argv) > 3 else None
     rows = []
     with open(path) as f:
         for row in csv.DictReader(f):
@@ -88,6 +97,40 @@ def main():
         avg = [(i, seqs[0][i][0], sum(q[i][1] for q in seqs) / nwin / 1e3) for i in range(len(seqs[0]))]
         for i, n, us in sorted(sorted(avg, key=lambda r: -r[2])[:24]):
             print(f"| {i} | {n.replace('skp_wino4_conv_c128_kernel', '')} | {us:.1f} |")
+    if conv_log:
+        conv_fraction(rows, bounds, nwin, conv_log)
+
+
+def conv_fraction(rows, bounds, nwin, conv_log):
+    """Time-weighted fraction of the fp32 matrix peak over every skp_wino4_* kernel of a step."""
+    short = lambda name: name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+    tot_f = tot_ns = 0.0
+    per = {}
+    for k in range(nwin):
+        lo, hi = bounds[-1 - nwin + k], bounds[-nwin + k]
+        win = [(st, en, short(name)) for st, en, name, _ in rows if st >= lo and en <= hi and "skp_wino4_" in name]
+        main = [w for w in win if "skp_wino4_conv" in w[2]]          # one per C-ABI call; reduce kernels only add time
+        if len(main) != len(conv_log):
+            print(f"\nconv log has {len(conv_log)} launches, step {k} of the trace {len(main)}: not the same configuration")
+            return
+        tot_ns += sum(en - st for st, en, _ in win)
+        tot_f += sum(l["algorithmic_flops"] for l in conv_log)
+        # attribute a reduce kernel to the conv launch in front of it
+        cur = None
+        for st, en, name in win:
+            if "skp_wino4_conv" in name:
+                cur = conv_log[main.index((st, en, name))]
+                key = (name.replace("skp_wino4_conv", ""), cur["Cin"], cur["Cout"], cur["H"], cur["W"], cur["B"])
+                d = per.setdefault(key, [0, 0.0, 0.0])
+                d[0] += 1; d[1] += cur["algorithmic_flops"]
+            if cur is not None:
+                per[key][2] += en - st
+    print(f"\nall skp_wino4_* kernels: {tot_f / nwin / 1e12:.3f} TFLOP executed (direct-form / 4) in {tot_ns / nwin / 1e6:.2f} ms per "
+          f"step => {tot_f / tot_ns / 1e3:.1f} TF/s = {tot_f / tot_ns / 1e3 / F32_MATRIX_PEAK_TF:.3f} of the {F32_MATRIX_PEAK_TF} TF/s "
+          "fp32 matrix peak (time-weighted over every launch)")
+    print("| kernel form | Cin->Cout @ HxW, rows | calls/step | ms/step | frac |\n|---|---|---|---|---|")
+    for (form, ci, co, H, W, B), (c, fl, ns) in sorted(per.items(), key=lambda kv: -kv[1][2])[:30]:
+        print(f"| {form} | {ci}->{co} @ {H}x{W}, {B} | {c / nwin:.1f} | {ns / nwin / 1e6:.2f} | {fl / ns / 1e3 / F32_MATRIX_PEAK_TF:.3f} |")
 
 
 if __name__ == "__main__":

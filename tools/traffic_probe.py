@@ -29,8 +29,19 @@ def main():
     x = torch.randn(Bc, ci, a.image_size, a.image_size, generator=g).to(dev)
     w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(dev)
     U = ops._wino4_filters(w, False)
-    for _ in range(a.iters):
-        ops._conv3x3_f4_raw(x, U, None, co)
+    lib, N = ops.N.lib(), ops.N
+    nblk = ops.conv3x3_stats_blocks(x.shape, w.shape)
+    if nblk and lib.skp_conv3x3_f4_gn_ok(Bc, ci, co, a.image_size, a.image_size):       # the form the step launches (bench.py conv_roofline)
+        y = torch.empty(Bc, co, a.image_size, a.image_size, device=dev)
+        stats = torch.empty(Bc, co, nblk, 2, device=dev)
+        coef = torch.stack([torch.full((Bc, ci), 0.7), torch.full((Bc, ci), 0.1)], dim=-1).to(dev).contiguous()
+        for _ in range(a.iters):
+            N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), None, None, y.data_ptr(), stats.data_ptr(), coef.data_ptr(),
+                                              Bc, ci, co, a.image_size, a.image_size, ops._stream()), "skp_conv3x3_f4_gn_f32")
+        del y, stats
+    else:
+        for _ in range(a.iters):
+            ops._conv3x3_f4_raw(x, U, None, co)
     del x
     sides = [16, 16, 16, 32]
     NT = (T + 15) // 16 * 16
