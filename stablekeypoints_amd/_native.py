@@ -13,7 +13,8 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 #                              that PyTorch-ROCm already loaded (one runtime per process, shared streams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libskp_hip.so")
+# SKP_LIB_PATH: another BUILD of the same library (same-box A/B of two kernel versions, tools/ab_build.py); never a fallback
+LIB_PATH = os.environ.get("SKP_LIB_PATH") or os.path.join(_HERE, "csrc", "libskp_hip.so")
 ABI_VERSION = 24
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64

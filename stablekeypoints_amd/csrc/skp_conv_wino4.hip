@@ -410,6 +410,9 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     int roff[6];
     bool lok, rok;
     int coff = SKP_OOB;                              // GNF: per-(image, channel) coefficients of the stage's channel `tc`
+    f32x2 mrow = {1.f, 1.f};                         // GNF: shift masks of patch rows 0 / 5 (0 outside the image) ...
+    f32x2 mcol = {1.f, 1.f};                         // ... and of patch columns 0 / 5 (the pair d[i][0]); fixed per unit
+    f32x2 gh_edge = {0.f, 0.f};                      // per stage: shift of the (c0, c5) pair in rows 1..4
     unsigned rowmask = 0;
     auto aim_transform = [&](int tb, bool valid) {   // point the transform role at tile block tb (nothing: every load returns 0)
         const int tg = tb * 16 + tl;
@@ -428,6 +431,10 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         lok = tx > 0;
         rok = tx + 1 < a.tilesX;
         coff = valid ? (b * a.Cin + tc) * 8 : SKP_OOB;
+        if (GNF) {
+            mrow = f32x2{(rowmask & 1u) ? 1.f : 0.f, (rowmask & 32u) ? 1.f : 0.f};
+            mcol = f32x2{lok ? 1.f : 0.f, rok ? 1.f : 0.f};
+        }
     };
     aim_transform(tblock, true);
     int cin_ld = zsplit * a.steps * 16;              // first input channel of the unit whose patches are being loaded
@@ -437,23 +444,28 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     f32x2 gcoef = {0.f, 0.f};
     f32x2 d[6][3];                                   // [row][column pair]: (c0,c5), (c1,c2), (c3,c4)
     auto gn_fetch = [&](int cin0) { if (GNF) gcoef = skp_buf_load_f32x2(crs, coff, cin0 * 8, 0); };
+    auto gn_prep = [&]() { if (GNF) gh_edge = f32x2{gcoef[1] * mcol[0], gcoef[1] * mcol[1]}; };
+    // GNF: v = x * s + h;  silu(v) = v * rcp(1 + 2^(-v log2 e)) on value PAIRS (the patch registers are column pairs): two
+    // packed fmas / muls, a packed add and a packed multiply per pair plus the four quarter-rate transcendentals -- an IEEE
+    // division here is ten VALU instructions per value, all of them added to the MFMA time.  Zero padding must stay zero
+    // although silu(0 * s + h) is not: a loaded 0 of an out-of-image row / column gets shift 0 as well.  Only patch rows 0 and 5
+    // and patch columns 0 and 5 can lie outside the image, so the shift is masked per (row class, column class) with float
+    // masks that are fixed per unit (aim_transform), four multiplies per stage instead of selects per row.
     auto gn_row = [&](int i) {                       // normalise + SiLU row i of the freshly loaded patch
         if (GNF) {
-            // v = x * s + h;  silu(v) = v * rcp(1 + 2^(-v log2 e)): the exponent is its own fma of x, and the quotient is
-            // v_rcp_f32 (1 ulp) -- an IEEE division here is ten VALU instructions per value, 360 per stage and thread, all of
-            // them added to the MFMA time
-            const bool rv = (rowmask >> i) & 1u;
-            const float sc = rv ? gcoef[0] : 0.f, sh = rv ? gcoef[1] : 0.f;
-            const float sl = lok ? sc : 0.f, hl = lok ? sh : 0.f, sr = rok ? sc : 0.f, hr = rok ? sh : 0.f;
-            auto act = [](float x, float s, float h) {
-                const float v = fmaf(x, s, h);
-                const float e = __builtin_amdgcn_exp2f(fmaf(x, -SKP_LOG2E * s, -SKP_LOG2E * h));
-                return v * __builtin_amdgcn_rcpf(1.0f + e);
+            const float rm = i == 0 ? mrow[0] : (i == 5 ? mrow[1] : 1.0f);
+            const f32x2 S2 = {gcoef[0], gcoef[0]};
+            const f32x2 Hm = {gcoef[1] * rm, gcoef[1] * rm};                 // rows 1..4: rm == 1 folds away
+            const f32x2 He = (i == 0 || i == 5) ? f32x2{gh_edge[0] * rm, gh_edge[1] * rm} : gh_edge;
+            auto act2 = [&](f32x2 x, f32x2 h) {
+                const f32x2 v = x * S2 + h;
+                const f32x2 z = v * (-SKP_LOG2E);
+                const f32x2 w = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + 1.0f;
+                return v * f32x2{__builtin_amdgcn_rcpf(w[0]), __builtin_amdgcn_rcpf(w[1])};
             };
-            d[i][0][0] = act(d[i][0][0], sl, hl);
-            d[i][0][1] = act(d[i][0][1], sr, hr);
-            d[i][1][0] = act(d[i][1][0], sc, sh); d[i][1][1] = act(d[i][1][1], sc, sh);
-            d[i][2][0] = act(d[i][2][0], sc, sh); d[i][2][1] = act(d[i][2][1], sc, sh);
+            d[i][0] = act2(d[i][0], He);
+            d[i][1] = act2(d[i][1], Hm);
+            d[i][2] = act2(d[i][2], Hm);
         }
     };
     auto load_row = [&](int cin0, int i) {
@@ -485,6 +497,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     gn_fetch(cin_ld);
 #pragma unroll
     for (int i = 0; i < 6; ++i) load_row(cin_ld, i);
+    gn_prep();
 #pragma unroll
     for (int i = 0; i < 6; ++i) gn_row(i);
 #pragma unroll
@@ -547,6 +560,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
                 }
                 if (p == 0) gn_fetch(cin_side);
                 if (p < 6) load_row(cin_side, p);
+                else if (GNF && p == 20) gn_prep();
                 else if (GNF && p >= 21 && p < 27) gn_row(p - 21);
                 else if (p >= 27 && p < 30) col_pass(p - 27);
                 else if (p >= 30) row_pass_store((bpar + s + 1) & 1, p - 30);

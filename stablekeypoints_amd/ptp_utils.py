@@ -121,6 +121,17 @@ def register_attention_control(model, controller, feature_upsample_res=256):
             batch_size, sequence_length, dim = x.shape
             is_cross = context is not None
             ctx = context if is_cross else x
+            stop = getattr(controller, "stop_after", None)
+            if (is_cross and stop is not None and sequence_length <= MAX_STORED_SEQ
+                    and len(controller.step_store["attn"]) + 1 >= min(stop, MAX_STORED_LAYERS)
+                    and len(controller.step_store["attn"]) < MAX_STORED_LAYERS):
+                # early exit: this is the LAST map the gate will store and the forward ends here (the caller discards the
+                # prediction, ptp_utils.py:246) -- the layer's value projection and attention output have no consumer
+                rec = FusedAttn(self.to_q(x), self.to_k(ctx), self.heads, self.scale, feature_upsample_res)
+                if getattr(controller, "materialize", False):
+                    rec = rec.materialize()
+                controller({"attn": rec}, is_cross, place_in_unet)
+                raise StopForward()
             if (not is_cross) and self.to_q.bias is None and self.to_k.bias is None and self.to_v.bias is None \
                     and "forward" not in self.to_q.__dict__:
                 q, k, v = ops.qkv_proj(x, self.to_q.weight, self.to_k.weight, self.to_v.weight)
