@@ -133,7 +133,7 @@ def _group_losses(controller, thetas, args, n):
     T = records[0].k.shape[1]
     n_cand = min(args.furthest_point_num_samples, T)
     K = min(args.top_k, n_cand)
-    if ops.map_bwd_sparse_supported(sides, K, records[0].R, T) and K >= 2:
+    if ops.map_bwd_sparse_supported(sides, K, records[0].R, T, records[0].heads) and K >= 2:
         meta = dict(R=records[0].R, heads=records[0].heads, scales=[r.scale for r in records],
                     thetas=[thetas[i].reshape(-1).tolist() for i in range(n)], sigma=args.sigma,
                     num_subjects=getattr(args, "num_subjects", 1), strategy=getattr(args, "top_k_strategy", "gaussian"),

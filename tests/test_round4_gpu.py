@@ -295,3 +295,58 @@ def test_sd15_config2_shape_step_vs_oracle():
     assert abs(eq_g.item() - ref_equiv) < 2e-3 * abs(ref_equiv)
     print("config-2 shape grad: |g|max", gref.abs().max().item(), "max abs diff", (c_gpu.grad.cpu() - gref).abs().max().item())
     torch.testing.assert_close(c_gpu.grad.cpu(), gref, rtol=5e-3, atol=5e-5 * gref.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# map backward without the dV staging (row bands)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    dict(sides=[16, 16, 16, 32], H=8, T=77, R=128, B=2, K=10),            # BASELINE config 2 launch shape: quads + pairs
+    dict(sides=[16, 32], H=8, T=128, R=128, B=1, K=16),                    # the kernel's largest T and K
+    dict(sides=[32], H=3, T=16, R=128, B=3, K=2),                          # one natural chunk, odd head count, pairs only
+    dict(sides=[32, 64], H=2, T=40, R=256, B=1, K=5),                      # R = 256: one column half per workgroup
+    dict(sides=[16], H=4, T=50, R=128, B=2, K=10),                         # T % 16 != 0: pad tokens in the last chunk
+])
+def test_band_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch):
+    """skp_attn_map_bwd_band_f32 (row bands, vertical adjoint in registers, no dV staging) against fp64 autograd through
+    F.interpolate(bicubic) + softmax, against the dense-gradient kernels and against the token-major sweep on the same
+    inputs; repeat run bit-identical; pad columns written as 0."""
+    from test_round3_gpu import _fp64_map_and_grad
+    from stablekeypoints_amd import ops
+    sides, H, T, R, B, K = (case[k] for k in ("sides", "H", "T", "R", "B", "K"))
+    assert ops.map_bwd_band_supported(sides, K, R, T, H)
+    g = torch.Generator().manual_seed(17)
+    NT = (T + 15) // 16 * 16
+    S = []
+    for s in sides:
+        S_l = torch.zeros(B, H, s * s, NT)
+        S_l[..., :T] = torch.randn(B, H, s * s, T, generator=g) * 3.0
+        S.append(S_l.cuda())
+    sel = torch.stack([torch.randperm(T, generator=g)[:K] for _ in range(B)]).cuda()
+    G = torch.randn(B, K, R, R, generator=g).cuda()
+    M, lse = ops._map_fwd(S, sides, B, H, T, R)
+    _, dz = _fp64_map_and_grad(S, sides, H, T, R, sel, G)
+    monkeypatch.setattr(ops, "MAP_BWD_MODE", "band")
+    dS = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
+    dS2 = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
+    dM = torch.zeros(B, T, R, R, device="cuda")
+    for b in range(B):
+        dM[b, sel[b]] = G[b]
+    dD = [torch.zeros_like(s_) for s_ in S]
+    ops._map_bwd(S, dD, sides, B, H, T, R, dM, lse)
+    dW = None
+    if max(sides) <= ops.MAP_SPARSE_MAX_SIDE:
+        monkeypatch.setattr(ops, "MAP_BWD_MODE", "sweep")
+        dW = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
+    for l in range(len(sides)):
+        ref = dz[l]
+        scale = ref.abs().max().item()
+        assert torch.equal(dS[l], dS2[l])                                     # deterministic
+        assert torch.isfinite(dS[l]).all() and (dS[l][..., T:] == 0).all()    # pad columns written as 0
+        err = (dS[l][..., :T].double() - ref).abs().max().item()
+        err_dense = (dD[l][..., :T].double() - ref).abs().max().item()
+        print(f"layer {l} (s={sides[l]}): |dz|max {scale:.3e}  band err {err / scale:.2e}  dense err {err_dense / scale:.2e}")
+        assert err < 2e-5 * scale
+        torch.testing.assert_close(dS[l][..., :T], dD[l][..., :T], rtol=1e-4, atol=2e-5 * scale)
+        if dW is not None:
+            torch.testing.assert_close(dS[l][..., :T], dW[l][..., :T], rtol=1e-4, atol=2e-5 * scale)
