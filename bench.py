@@ -621,7 +621,7 @@ def main():
             issue1, issue2 = ops.mfma_issue_rate(1, device=dev), ops.mfma_issue_rate(2, device=dev)
         except Exception as e:                                    # noqa: BLE001 -- the line of record does not depend on the probe
             print(f"bench.py: MFMA issue-rate probe unavailable ({e})", file=sys.stderr)
-            issue1 = issue2 = float("nan")
+            issue1 = issue2 = None
         conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}")
         if conv_traffic is None:                                 # committed passes from before the kernel became persistent: same
             conv_traffic, conv_src = measured_traffic("skp_wino4_conv_c128_kernel@grid2097152")    # launch shape, one workgroup per unit
@@ -683,7 +683,7 @@ def main():
                          "direct_form_flops": cv_direct, "direct_form_equiv_tflops": cv_direct / cv_t / 1e12,
                          "rows_per_launch": cv_rows, "dtype": "f32 (v_mfma_f32_16x16x4_f32)",
                          "peak_note": "frac is against the NOMINAL 157.3 TF/s; mfma_issue_ceiling gives what back-to-back fp32 MFMAs "
-                                      f"retire on this box ({issue1:.1f} TF/s at one wave per SIMD, which is what this kernel holds)",
+                                      f"retire on this box ({'%.1f TF/s' % issue1 if issue1 else 'not measured'} at one wave per SIMD, which is what this kernel holds)",
                          "step_forms": cv_forms, "conv_all_launches": conv_all},
             # the north-star attention kernel (BASELINE metric: "fraction of the attention roofline")
             "roofline_attn_map": {"kernel": kt["fwd_kernel"] + " (fused up-res softmax map, forward)", "bwd_route": kt["bwd_route"],
