@@ -108,18 +108,17 @@ int skp_attn_map_fwd_wide_f32(const float* const* S /*[host]*/, const int* s /*[
  * the host-side gate callers use to choose between it and the two-pass token-group route (host logic, no launch). */
 int skp_attn_map_fwd_wide_ok(const int* s /*[host]*/, int L, int T, int R);
 
-/* T <= 128 route of the sparse-gradient backward WITHOUT any dV staging (csrc/skp_attn_map_band.hip, round 4): row bands, the
- * vertical adjoint of the bicubic accumulated in registers while a lane sweeps its column, the horizontal adjoint once per
- * band and low-res row.  Same arguments and result as skp_attn_map_bwd_sparse_f32 (sel [B,K] int64, G [B,K,R,R] = the K
- * non-zero rows of dM, lse from the forward; dS[l] written for every row, columns t < 16*ceil(T/16)).
- * skp_attn_map_bwd_band_ok: 1 when the shapes are served -- R in {128, 256}, every layer R = k*s with k in {4, 8},
- * s % (512 / R) == 0, T <= 128, K <= 16 (the SD-1.x hooked layers at feature_upsample_res 128 / 256) -- else 0 (host logic).
- * workspace: skp_attn_map_bwd_band_workspace() bytes (band partials, 2 x the dS bytes at R = 128). */
-int skp_attn_map_bwd_band_ok(const int* s /*[host]*/, int L, int H, int T, int R, int K);
-int64_t skp_attn_map_bwd_band_workspace(const int* s /*[host]*/, int L, int B, int H, int T, int R, int K);
-int skp_attn_map_bwd_band_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/, int L,
-                              int B, int H, int T, int R, const int64_t* sel, const float* G, int K, const float* lse,
-                              void* workspace, int ldt, void* stream);
+/* "Column sweep" form of the T <= 128 sparse-gradient backward (csrc/skp_attn_map_col.hip, round 4): a workgroup sweeps all R rows
+ * of one (batch row, layer, head, 8-token chunk), the vertical adjoint lives in a four-row register window and the horizontal
+ * adjoint is applied to COMPLETE low-res rows only -- no dV staging, no band partials, dS written once.  Same arguments and
+ * result as skp_attn_map_bwd_sparse_f32.  skp_attn_map_bwd_col_ok: 1 when served (R in {128, 256}, every layer R = k*s with
+ * k in {4, 8}, 8 <= s <= 64, T <= 128, K <= 16), else 0 (host logic).  workspace: skp_attn_map_bwd_col_workspace() bytes
+ * (dot = sum_k p_k g_k per (layer, head, pixel) + the selected tokens' part). */
+int skp_attn_map_bwd_col_ok(const int* s /*[host]*/, int L, int H, int T, int R, int K);
+int64_t skp_attn_map_bwd_col_workspace(const int* s /*[host]*/, int L, int B, int H, int T, int R, int K);
+int skp_attn_map_bwd_col_f32(const float* const* S /*[host]*/, float* const* dS /*[host]*/, const int* s /*[host]*/, int L,
+                             int B, int H, int T, int R, const int64_t* sel, const float* G, int K, const float* lse,
+                             void* workspace, int ldt, void* stream);
 
 /* Backward of the fused map for a SPARSE map gradient: the losses of optimize.py:157-206 index the map with the K
  * selected tokens (optimize.py:395-414), so dM is non-zero on K rows per batch row only.

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKP_LIB_PATH: another BUILD of the same library (same-box A/B of two kernel versions, tools/ab_build.py); never a fallback
 LIB_PATH = os.environ.get("SKP_LIB_PATH") or os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 27
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -37,10 +37,10 @@ SIGNATURES = {
     "skp_unwarp_accumulate_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "skp_attn_map_fwd_wide_f32": [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "skp_attn_map_fwd_wide_ok": [C.POINTER(_i), _i, _i, _i],
-    "skp_attn_map_bwd_band_ok": [C.POINTER(_i), _i, _i, _i, _i, _i],
-    "skp_attn_map_bwd_band_workspace": [C.POINTER(_i), _i, _i, _i, _i, _i, _i],
-    "skp_attn_map_bwd_band_f32": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp,
-                                  _i, _vp],
+    "skp_attn_map_bwd_col_ok": [C.POINTER(_i), _i, _i, _i, _i, _i],
+    "skp_attn_map_bwd_col_workspace": [C.POINTER(_i), _i, _i, _i, _i, _i, _i],
+    "skp_attn_map_bwd_col_f32": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp,
+                                 _i, _vp],
     "skp_attn_map_bwd_sparse_workspace": [C.POINTER(_i), _i, _i, _i, _i, _i, _i],
     "skp_attn_map_bwd_sparse_f32": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp,
                                     _i, _vp],

@@ -148,28 +148,31 @@ def _map_bwd(S, dS, sides, B, H, T, R, dM, lse):
         launch(t0, t1, 2, dot)
 
 
-# Which map backward the fused step takes.  "auto": the token-major sweep over sparse gradient rows when T > 128 (one pass
-# instead of token groups x two passes: 2.4 vs 7.9 ms at T = 500, B = 8), the dense-gradient kernels for T <= 128 (0.54 ms
-# at T = 77 against 0.64 ms for the sweep and 0.78 ms for the row-band kernel of round 4, profiles/r04_map_band.md);
-# "band" / "sweep" force one sparse kernel where it serves the shapes, "sparse" = either, "dense" forces the dense route.
+# Which map backward the fused step takes.  The losses give the map gradient as K selected rows per batch row; "auto" hands
+# it over in that form (one map+losses node, ops.MapLossesFn) wherever a sparse kernel is the faster route:
+#   T <= 128: the column sweep (csrc/skp_attn_map_col.hip, round 4: vertical adjoint in a register window, horizontal adjoint on
+#             complete low-res rows, no dV staging) where it serves the shapes -- 381 us against 541 us for the dense kernels at
+#             the step's shape; other shapes at T <= 128 keep the dense-gradient kernels (the token-major sweep: 636 us);
+#   T > 128:  the token-major sweep (2.4 vs 7.9 ms at T = 500, B = 8: one pass instead of token groups x two passes).
+# "col" / "sweep" force one sparse kernel where it serves the shapes, "sparse" = either, "dense" forces the dense route.
 MAP_BWD_MODE = os.environ.get("SKP_MAP_BWD", "auto")
 MAP_SPARSE_MAX_SIDE, MAP_SPARSE_MAX_K, MAP_SPARSE_MAX_R = 32, 32, 1024     # limits of csrc/skp_attn_map_tok.hip
 
 
-def map_bwd_band_supported(sides, K: int, R: int, T: int, heads: int = 8) -> bool:
+def map_bwd_col_supported(sides, K: int, R: int, T: int, heads: int = 8) -> bool:
     si, _keep = N.int_array([int(v) for v in sides])
-    return bool(N.lib().skp_attn_map_bwd_band_ok(si, len(sides), int(heads), int(T), int(R), int(K)))
+    return bool(N.lib().skp_attn_map_bwd_col_ok(si, len(sides), int(heads), int(T), int(R), int(K)))
 
 
 def map_bwd_sparse_supported(sides, K: int, R: int, T: int = 10 ** 9, heads: int = 8) -> bool:
     if MAP_BWD_MODE == "dense":
         return False
-    band = MAP_BWD_MODE != "sweep" and T <= TOKEN_GROUP and map_bwd_band_supported(sides, K, R, T, heads)
-    sweep = (MAP_BWD_MODE != "band" and max(sides) <= MAP_SPARSE_MAX_SIDE and 1 <= K <= MAP_SPARSE_MAX_K
+    col = MAP_BWD_MODE != "sweep" and T <= TOKEN_GROUP and map_bwd_col_supported(sides, K, R, T, heads)
+    sweep = (MAP_BWD_MODE != "col" and max(sides) <= MAP_SPARSE_MAX_SIDE and 1 <= K <= MAP_SPARSE_MAX_K
              and R <= MAP_SPARSE_MAX_R)
     if MAP_BWD_MODE == "auto":
-        return sweep and T > TOKEN_GROUP              # at T <= 128 both sparse kernels are slower than the dense route
-    return band or sweep
+        return col or (sweep and T > TOKEN_GROUP)     # at T <= 128 the token-major sweep is slower than the dense route
+    return col or sweep
 
 
 def _map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse):
@@ -181,15 +184,15 @@ def _map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse):
     dS = [torch.empty_like(s_) for s_ in S]
     si, _k0 = N.int_array(sides)
     lib = N.lib()
-    if MAP_BWD_MODE in ("band", "sparse") and T <= TOKEN_GROUP and map_bwd_band_supported(sides, K, R, T, H):
-        nbytes = lib.skp_attn_map_bwd_band_workspace(si, L, B, H, T, R, K)
+    if MAP_BWD_MODE != "sweep" and T <= TOKEN_GROUP and map_bwd_col_supported(sides, K, R, T, H):
+        nbytes = lib.skp_attn_map_bwd_col_workspace(si, L, B, H, T, R, K)
         if nbytes < 0:
-            N.check(int(nbytes), "skp_attn_map_bwd_band_workspace")
+            N.check(int(nbytes), "skp_attn_map_bwd_col_workspace")
         ws = torch.empty((nbytes + 3) // 4, device=G.device, dtype=torch.float32)
         sp, _k1 = N.ptr_array([t.data_ptr() for t in S])
         dp, _k2 = N.ptr_array([t.data_ptr() for t in dS])
-        N.check(lib.skp_attn_map_bwd_band_f32(sp, dp, si, L, B, H, T, R, sel.data_ptr(), G.data_ptr(), K, lse.data_ptr(),
-                                              ws.data_ptr(), ldt, _stream()), "skp_attn_map_bwd_band_f32")
+        N.check(lib.skp_attn_map_bwd_col_f32(sp, dp, si, L, B, H, T, R, sel.data_ptr(), G.data_ptr(), K, lse.data_ptr(),
+                                             ws.data_ptr(), ldt, _stream()), "skp_attn_map_bwd_col_f32")
         if ldt > (T + 15) // 16 * 16:
             for d_ in dS:
                 d_[..., (T + 15) // 16 * 16:] = 0

@@ -256,7 +256,7 @@ def test_sparse_map_backward_vs_fp64_and_dense(case, monkeypatch):
     """skp_attn_map_bwd_sparse_f32 (token-major sweep, sparse gradient rows) against fp64 autograd through
     F.interpolate(bicubic) + softmax, and against the dense-gradient kernels on the same inputs; repeat run bit-identical."""
     from stablekeypoints_amd import ops
-    monkeypatch.setattr(ops, "MAP_BWD_MODE", "sweep")            # this test is the token-major sweep's (band kernel: round 4)
+    monkeypatch.setattr(ops, "MAP_BWD_MODE", "sweep")            # this test is the token-major sweep's (column sweep: round 4)
     if "bands" in case:
         monkeypatch.setenv("SKP_MAP_BANDS", str(case["bands"]))
     sides, H, T, R, B, K = (case[k] for k in ("sides", "H", "T", "R", "B", "K"))

@@ -298,7 +298,7 @@ def test_sd15_config2_shape_step_vs_oracle():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# map backward without the dV staging (row bands)
+# map backward without the dV staging (column sweep)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", [
     dict(sides=[16, 16, 16, 32], H=8, T=77, R=128, B=2, K=10),            # BASELINE config 2 launch shape: quads + pairs
@@ -307,14 +307,15 @@ def test_sd15_config2_shape_step_vs_oracle():
     dict(sides=[32, 64], H=2, T=40, R=256, B=1, K=5),                      # R = 256: one column half per workgroup
     dict(sides=[16], H=4, T=50, R=128, B=2, K=10),                         # T % 16 != 0: pad tokens in the last chunk
 ])
-def test_band_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch):
-    """skp_attn_map_bwd_band_f32 (row bands, vertical adjoint in registers, no dV staging) against fp64 autograd through
+def test_column_sweep_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch, route="col"):
+    """skp_attn_map_bwd_col_f32 (column sweep: vertical adjoint in a register window, horizontal adjoint on complete low-res
+    rows, no dV staging; the T <= 128 route of the step since round 4) against fp64 autograd through
     F.interpolate(bicubic) + softmax, against the dense-gradient kernels and against the token-major sweep on the same
     inputs; repeat run bit-identical; pad columns written as 0."""
     from test_round3_gpu import _fp64_map_and_grad
     from stablekeypoints_amd import ops
     sides, H, T, R, B, K = (case[k] for k in ("sides", "H", "T", "R", "B", "K"))
-    assert ops.map_bwd_band_supported(sides, K, R, T, H)
+    assert ops.map_bwd_col_supported(sides, K, R, T, H)
     g = torch.Generator().manual_seed(17)
     NT = (T + 15) // 16 * 16
     S = []
@@ -326,7 +327,7 @@ def test_band_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch):
     G = torch.randn(B, K, R, R, generator=g).cuda()
     M, lse = ops._map_fwd(S, sides, B, H, T, R)
     _, dz = _fp64_map_and_grad(S, sides, H, T, R, sel, G)
-    monkeypatch.setattr(ops, "MAP_BWD_MODE", "band")
+    monkeypatch.setattr(ops, "MAP_BWD_MODE", route)
     dS = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
     dS2 = ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse)
     dM = torch.zeros(B, T, R, R, device="cuda")
@@ -345,7 +346,7 @@ def test_band_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch):
         assert torch.isfinite(dS[l]).all() and (dS[l][..., T:] == 0).all()    # pad columns written as 0
         err = (dS[l][..., :T].double() - ref).abs().max().item()
         err_dense = (dD[l][..., :T].double() - ref).abs().max().item()
-        print(f"layer {l} (s={sides[l]}): |dz|max {scale:.3e}  band err {err / scale:.2e}  dense err {err_dense / scale:.2e}")
+        print(f"layer {l} (s={sides[l]}): |dz|max {scale:.3e}  {route} err {err / scale:.2e}  dense err {err_dense / scale:.2e}")
         assert err < 2e-5 * scale
         torch.testing.assert_close(dS[l][..., :T], dD[l][..., :T], rtol=1e-4, atol=2e-5 * scale)
         if dW is not None:

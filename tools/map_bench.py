@@ -65,9 +65,9 @@ def main():
     if not a.skip_dense:
         dD = [torch.zeros_like(x) for x in S]
         timed("map backward, dense gradient (A + B)", lambda: ops._map_bwd(S, dD, sides, B, H, T, R, dM, lse), a.iters)
-    if ops.map_bwd_band_supported(sides, K, R, T, H):
-        ops.MAP_BWD_MODE = "band"
-        timed("map backward, sparse gradient (row bands)", lambda: ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse), a.iters)
+    if ops.map_bwd_col_supported(sides, K, R, T, H):
+        ops.MAP_BWD_MODE = "col"
+        timed("map backward, sparse gradient (column sweep)", lambda: ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse), a.iters)
     ops.MAP_BWD_MODE = "sweep"
     timed("map backward, sparse gradient (token-major)", lambda: ops._map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse), a.iters)
     if not a.skip_dense:
