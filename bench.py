@@ -142,7 +142,8 @@ def map_kernel_roofline(ops, B, T, R, iters, device, layer_dims=None, top_k=10):
     flops_equiv = B * sum(2 * R * R * C * T for _, C in dims)   # the reference's direct up-res contraction
     out["fwd_kernel"] = ("skp_attn_map_fwd_wide_kernel (one pass, token slices)" if ops.map_wide_supported(T, R) else
                          "skp_attn_map_fwd_kernel" + (" (token groups x two passes)" if T > 128 else ""))
-    out["bwd_route"] = (("sparse gradient rows, column sweep (skp_map_bwd_col_kernel: no dV staging)" if T <= 128 else
+    out["bwd_route"] = (("sparse gradient rows, column sweep (skp_map_bwd_col_kernel: no dV staging)"
+                         if T <= ops.COL_MAX_T and ops.map_bwd_col_supported(sides, Kk, R, T, H) else
                          "sparse gradient rows, token-major sweep (skp_map_bwd_tok_kernel)") if sparse else
                         "dense gradient (skp_attn_map_bwd_kernel + vadj)")
     return out, fwd_bytes, bwd_bytes, flops_equiv

@@ -22,7 +22,7 @@
 // (a small side buffer); then the natural 8-token chunks with f_t = -p_t dot, which write dS and add the selected tokens'
 // part on the way out.  HBM-side: lse + dot re-read per chunk from L2 / MALL, dS written once; nothing staged.
 //
-// Shapes served (skp_attn_map_bwd_col_ok): R in {128, 256}, every layer R = k s with k in {4, 8} and s >= 8, T <= 128, K <= 16
+// Shapes served (skp_attn_map_bwd_col_ok): R in {128, 256}, every layer R = k s with k in {4, 8} and s >= 8, T <= 1024, K <= 16
 // -- the SD-1.x path at feature_upsample_res 128 / 256; everything else keeps the other routes.
 #include "skp_common.h"
 #include <stdlib.h>
@@ -418,7 +418,7 @@ int col_k2(int R, int s) {
 }  // namespace
 
 extern "C" int skp_attn_map_bwd_col_ok(const int* s, int L, int H, int T, int R, int K) {
-    if (!s || L <= 0 || L > SKP_MAX_LAYERS || H <= 0 || T <= 0 || T > 128 || K <= 0 || K > CL_KMAX) return 0;
+    if (!s || L <= 0 || L > SKP_MAX_LAYERS || H <= 0 || T <= 0 || T > 1024 || K <= 0 || K > CL_KMAX) return 0;
     if (R != 128 && R != 256) return 0;
     for (int l = 0; l < L; ++l)
         if (!col_k2(R, s[l]) || s[l] > 64 || (s[l] & 3)) return 0;

@@ -150,13 +150,15 @@ def _map_bwd(S, dS, sides, B, H, T, R, dM, lse):
 
 # Which map backward the fused step takes.  The losses give the map gradient as K selected rows per batch row; "auto" hands
 # it over in that form (one map+losses node, ops.MapLossesFn) wherever a sparse kernel is the faster route:
-#   T <= 128: the column sweep (csrc/skp_attn_map_col.hip, round 4: vertical adjoint in a register window, horizontal adjoint on
-#             complete low-res rows, no dV staging) where it serves the shapes -- 381 us against 541 us for the dense kernels at
-#             the step's shape; other shapes at T <= 128 keep the dense-gradient kernels (the token-major sweep: 636 us);
-#   T > 128:  the token-major sweep (2.4 vs 7.9 ms at T = 500, B = 8: one pass instead of token groups x two passes).
+#   the column sweep (csrc/skp_attn_map_col.hip, round 4: vertical adjoint in a register window, horizontal adjoint on complete
+#   low-res rows, no dV staging) wherever it serves the shapes (R in {128, 256}, R / s in {4, 8}, K <= 16, any T <= 1024):
+#   377 us against 541 us for the dense kernels at T = 77, 1.56 ms against 2.47 ms for the token-major sweep at T = 500;
+#   other shapes: T <= 128 the dense-gradient kernels (the token-major sweep is slower there: 636 us), T > 128 the
+#   token-major sweep (2.4 vs 7.9 ms at T = 500, B = 8, for token groups x two passes of the dense kernels).
 # "col" / "sweep" force one sparse kernel where it serves the shapes, "sparse" = either, "dense" forces the dense route.
 MAP_BWD_MODE = os.environ.get("SKP_MAP_BWD", "auto")
 MAP_SPARSE_MAX_SIDE, MAP_SPARSE_MAX_K, MAP_SPARSE_MAX_R = 32, 32, 1024     # limits of csrc/skp_attn_map_tok.hip
+COL_MAX_T = int(os.environ.get("SKP_MAP_COL_MAX_T", "1024"))                 # token counts the column sweep is taken for (A/B: 128)
 
 
 def map_bwd_col_supported(sides, K: int, R: int, T: int, heads: int = 8) -> bool:
@@ -167,7 +169,7 @@ def map_bwd_col_supported(sides, K: int, R: int, T: int, heads: int = 8) -> bool
 def map_bwd_sparse_supported(sides, K: int, R: int, T: int = 10 ** 9, heads: int = 8) -> bool:
     if MAP_BWD_MODE == "dense":
         return False
-    col = MAP_BWD_MODE != "sweep" and T <= TOKEN_GROUP and map_bwd_col_supported(sides, K, R, T, heads)
+    col = MAP_BWD_MODE != "sweep" and T <= COL_MAX_T and map_bwd_col_supported(sides, K, R, T, heads)
     sweep = (MAP_BWD_MODE != "col" and max(sides) <= MAP_SPARSE_MAX_SIDE and 1 <= K <= MAP_SPARSE_MAX_K
              and R <= MAP_SPARSE_MAX_R)
     if MAP_BWD_MODE == "auto":
@@ -184,7 +186,7 @@ def _map_bwd_sparse(S, sides, B, H, T, R, sel, G, lse):
     dS = [torch.empty_like(s_) for s_ in S]
     si, _k0 = N.int_array(sides)
     lib = N.lib()
-    if MAP_BWD_MODE != "sweep" and T <= TOKEN_GROUP and map_bwd_col_supported(sides, K, R, T, H):
+    if MAP_BWD_MODE != "sweep" and T <= COL_MAX_T and map_bwd_col_supported(sides, K, R, T, H):
         nbytes = lib.skp_attn_map_bwd_col_workspace(si, L, B, H, T, R, K)
         if nbytes < 0:
             N.check(int(nbytes), "skp_attn_map_bwd_col_workspace")

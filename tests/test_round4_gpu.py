@@ -306,6 +306,7 @@ def test_sd15_config2_shape_step_vs_oracle():
     dict(sides=[32], H=3, T=16, R=128, B=3, K=2),                          # one natural chunk, odd head count, pairs only
     dict(sides=[32, 64], H=2, T=40, R=256, B=1, K=5),                      # R = 256: one column half per workgroup
     dict(sides=[16], H=4, T=50, R=128, B=2, K=10),                         # T % 16 != 0: pad tokens in the last chunk
+    dict(sides=[16, 32], H=8, T=300, R=128, B=1, K=10),                    # a wide token axis (the wide forward gives lse)
 ])
 def test_column_sweep_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch, route="col"):
     """skp_attn_map_bwd_col_f32 (column sweep: vertical adjoint in a register window, horizontal adjoint on complete low-res
@@ -316,6 +317,7 @@ def test_column_sweep_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch, ro
     from stablekeypoints_amd import ops
     sides, H, T, R, B, K = (case[k] for k in ("sides", "H", "T", "R", "B", "K"))
     assert ops.map_bwd_col_supported(sides, K, R, T, H)
+    monkeypatch.setattr(ops, "COL_MAX_T", 1024)
     g = torch.Generator().manual_seed(17)
     NT = (T + 15) // 16 * 16
     S = []
