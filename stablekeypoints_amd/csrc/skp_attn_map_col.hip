@@ -35,11 +35,14 @@ constexpr int CL_TS = CL_TC + 4;     // token stride of the V rows (16-byte alig
 constexpr int CL_PS = CL_TC + 1;     // token stride of the exchange buffer
 constexpr int CL_LUSE = 10;          // list entries read per low-res column (<= 9 real + padding pointing at a zero slot)
 constexpr int CL_KMAX = 16;
-#ifndef CL_PF_LSE
-#define CL_PF_LSE 0                  // the next group's lse / dot loads in flight under the current group's rows
+// Prefetch of the next group's lse / dot and V-phase loads under the current group's rows: costs 8 + 16 registers.  The natural
+// pass cannot afford them (measured: 601 us with the lse prefetch against 537 without at 168 registers) and the selected-token
+// pass (512 two-wave workgroups, one wave per SIMD) does not gain from them (394 us either way on one box): both off.
+#ifndef CL_PF_SEL
+#define CL_PF_SEL 0
 #endif
-#ifndef CL_PF_V
-#define CL_PF_V 0                    // ... and its V-phase loads (16 registers held across the rows)
+#ifndef CL_PF_NAT
+#define CL_PF_NAT 0
 #endif
 // Waves per SIMD the register budgets are held to.  Measured (B = 8, T = 77, R = 128; us for the whole backward): natural pass at
 // 4 / 3 / 2 waves per SIMD 942 / 535 / 381 -- below 240 registers the allocator spills the accumulator window inside the row
@@ -227,7 +230,7 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
 
     // the K2 rows of group gg (V rows in Vg[buf]); tap j accumulates into window slot j (rows floor(src_y) - 1 .. + 2)
     float lse_r[K2], nd_r[K2];                   // lse and -dot (or 1 / (L H)) of the current group's rows
-    float lse_n[K2], d0_n[K2], d1_n[K2];         // ... of the next group, in flight while the current rows run (CL_PF_LSE)
+    float lse_n[K2], d0_n[K2], d1_n[K2];         // ... of the next group, in flight while the current rows run (PF)
     auto ln_issue = [&](int gg) {
 #pragma unroll
         for (int r = 0; r < K2; ++r) {
@@ -349,24 +352,15 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
     // one group: sweep its rows, then build the next group's V rows (loads + combine back to back: holding the loads in
     // registers across the rows made the allocator spill them, with a wait for every load; the ~8 resident workgroups of a CU
     // cover each other's latency instead), barrier
+    constexpr bool PF = SEL ? (CL_PF_SEL != 0) : (CL_PF_NAT != 0);
     auto group = [&](int gg) {
         const bool more = gg + 1 < 2 * s;
-#if CL_PF_LSE
-        if (more) ln_issue(gg + 1);
-#else
-        ln_issue(gg); ln_take();
-#endif
-#if CL_PF_V
-        if (more) v_issue(gg + 1);
-#endif
+        if (PF) { if (more) { ln_issue(gg + 1); v_issue(gg + 1); } }
+        else { ln_issue(gg); ln_take(); }
         rows(gg, gg & 1);
-#if !CL_PF_V
-        if (more) v_issue(gg + 1);
-#endif
+        if (!PF && more) v_issue(gg + 1);
         if (more) v_store(gg + 1, (gg + 1) & 1);
-#if CL_PF_LSE
-        if (more) ln_take();
-#endif
+        if (PF && more) ln_take();
         __syncthreads();
     };
 
@@ -376,9 +370,7 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
     // unrolled slot index keeps ONE instance of the row code: fourteen instances were 64 KB of instructions).
     v_issue(0);
     v_store(0, 0);
-#if CL_PF_LSE
-    ln_issue(0); ln_take();
-#endif
+    if (PF) { ln_issue(0); ln_take(); }
     __syncthreads();
     group(0);
     fold(2);                                      // row -2 -> row 0 (slot 2 at fl = -1)
