@@ -455,6 +455,7 @@ def verify_against_oracle(ldm_cpu, ldm, controller, a, dev):
     lg, eg, sg = group_step(ldm, image, c_gpu, args, controller, RandomAffineWithInverse(), denom=1, noise=noise.to(dev),
                             thetas=theta)
     gref, ggpu = c_ref.grad, c_gpu.grad.cpu()
+    loss, sharp, equiv, lg, sg, eg = (torch.as_tensor(v).detach() for v in (loss, sharp, equiv, lg, sg, eg))
     return {"what": f"1 image {size}x{size}, T={a.tokens}, R={a.res}: oracle reference-order CPU step vs the MI355X step, same "
                     "host-drawn weights / noise / affine",
             "loss_cpu": float(loss), "loss_gpu": float(lg), "loss_rel_diff": abs(float(lg) - float(loss)) / abs(float(loss)),
