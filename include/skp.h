@@ -155,6 +155,22 @@ int skp_conv3x3_f4_gn_ok(int B, int Cin, int Cout, int H, int W);
 int skp_conv3x3_f4_gn_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, float* stats,
                           const float* coef, int B, int Cin, int Cout, int H, int W, void* stream);
 
+/* The same convolution (diffusers ResnetBlock2D.conv1 / conv2 of the UNet's 8^2 .. 16^2 levels, reached from
+ * ptp_utils.py:213-217) for SMALL spatial sizes with many channels, where the F(4x4,3x3) kernels above are bound by their
+ * filter stream (36 transformed values per channel pair for a handful of tiles): the filter stays as its 9 taps
+ * (skp_conv3x3_f4r_filter_f32: R, 9 * Cin * Cout floats, in MFMA operand order; flip_transpose as above), G g G^T is applied
+ * by the lanes on the way into the matrix cores, and the input transform runs once per launch into the workspace.
+ * Shapes the kernel RUNS: Cin % 16 == 0, Cout % 64 == 0, H, W % 4 == 0 (else SKP_E_RANGE).  skp_conv3x3_f4r_ok: 1 where
+ * it also PAYS against the kernels above (measured: <= 128 tiles with >= 1280 channels on both sides, <= 512 tiles with
+ * >= 1920 on one; SKP_WINO_RAW=0 turns it off) -- the rule the Python layer routes by.  workspace:
+ * skp_conv3x3_f4r_workspace() bytes, REQUIRED (pre-transformed input + K-split partials).  fp32, fixed K-split order
+ * (bit-reproducible). */
+int skp_conv3x3_f4r_ok(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4r_filter_f32(const void* w, void* R, int Cout, int Cin, int flip_transpose, void* stream);
+int64_t skp_conv3x3_f4r_workspace(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bias, const void* residual, void* y, void* workspace,
+                        int B, int Cin, int Cout, int H, int W, void* stream);
+
 /* Ordinary cross-attention core (ptp_utils.py:493-506,540) for a short key axis, fp32 MFMA, K/V staged in
  * LDS, softmax over the tokens in registers:
  *   out[b,n,h*d+c] = sum_t softmax_t(scale * q[b,n,h,:].k[bk,t,h,:]) * v[bk,t,h*d+c]

@@ -79,3 +79,7 @@ __device__ void skp_buf_store_f32(float v, i32x4 rsrc, int voffset, int soffset,
 __device__ void skp_buf_store_f32x2(f32x2 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 __device__ void skp_buf_store_f32x4(f32x4 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 #define SKP_OOB ((int)0x80000000)      /* loads return 0, stores are dropped */
+// LDS DMA: `size` bytes per lane (4, 12 or 16) from rsrc[voffset + soffset + offset] straight to LDS at (wave-uniform) lds + lane * size;
+// counted by vmcnt, no staging registers.  size / offset / aux must be compile-time constants.
+typedef __attribute__((address_space(3))) void* skp_lds_ptr;
+__device__ void skp_buf_load_lds(i32x4 rsrc, skp_lds_ptr lds, int size, int voffset, int soffset, int offset, int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");

@@ -86,6 +86,7 @@ struct Wino4Args {
     float* stats;               // optional [B][Cout][tilesPerImg/16][2] = {mean, sum (y - mean)^2} per 16-tile block (next GroupNorm), or null
     int sblk;                   // 16-tile blocks per image
     const float* gncoef;        // GNF kernels: [B][Cin][2] = (scale, shift) of the GroupNorm(+offset) in front of this convolution
+    int vpad;                   // raw-filter form: tiles per row of the pre-transformed input (tile blocks x 32)
 };
 
 // Block statistics without register pressure: every lane parks {mean, M2 = sum (y - mean)^2} of its 4x4 outputs -- taken
@@ -376,6 +377,246 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
         if (tid < 128) {
             const int wv = tid >> 5, tb = (tid >> 4) & 1, lc = tid & 15;
             w4_store_stats(a, (const f32x2*)vst, wv * 8 + (lc & 3) * 2 + tb, lc >> 2, tile0 + tb * 16, (cg * 4 + wv) * 16 + lc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Raw-filter form for the small-spatial UNet layers (8^2 .. 32^2 at 8 rows: 32 .. 512 tiles against 640 .. 2560 channels).
+// There the kernels above are bound by their FILTER stream, not by the matrix cores: every workgroup pulls 36 transformed
+// values per (cin, cout) pair for at most a few tile blocks (1280 -> 1280 at 8^2: 236 MB per launch from HBM for 3.8 GF).
+// Here the filter stays as the 9 taps it is (4x fewer bytes) and G g G^T is applied by the lane that owns the pair, on its
+// way into the MFMA A operand; the INPUT transform moves out of the kernel instead (skp_wino4r_input_kernel, once per launch
+// for all channel groups: with 10 - 40 channel groups the in-kernel transform was redone that many times), so the stage loop
+// has no patch loads, no transform role and no LDS writes: the transformed tiles of the next stage arrive by LDS DMA
+// (buffer_load ... lds, no registers), the next stage's taps in 9 registers quads.
+//   U = (D G') g (D G')^T with G' = [1 0 0; 1 1 1; 1 -1 1; 1 2 4; 1 -2 4; 0 0 1], D = diag(1/4, -1/6, -1/6, 1/24, 1/24, 1):
+//   the scales d_i d_j are folded into the pre-transformed input, the lanes apply the small-integer G' only
+//   (60 four-wide VALU operations per stage and lane against 288 MFMAs).
+// Layouts:  Rw[Cin/16][Cout/16][9 taps][kq][i16][m]   (cin = 16 c16 + 4 kq + m, cout = 16 cb + i16): one 1 KB row per load
+//           Vg[Cin/16][36][kq][vpad tiles][m]          scaled B^T d B, zero in the padding tiles
+// Workgroup = 64 output channels x 32 tiles (wave: 16 x 32, 288 accumulators), K splits and work order as skp_wino4_conv_kernel.
+__global__ void skp_wino4r_filter_kernel(const float* __restrict__ w, float* __restrict__ R, int Cout, int Cin, int flip_t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Cout * Cin) return;
+    const int co = idx / Cin, ci = idx - co * Cin;
+    const int c16 = ci >> 4, kq = (ci >> 2) & 3, m = ci & 3, cb = co >> 4, i16 = co & 15, CB = Cout >> 4;
+    float* dst = R + ((size_t)(c16 * CB + cb) * 9 * 64 + kq * 16 + i16) * 4 + m;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float v = flip_t ? w[((size_t)ci * Cout + co) * 9 + (8 - t)] : w[((size_t)co * Cin + ci) * 9 + t];
+        dst[t * 256] = v;
+    }
+}
+
+// Vg = scaled input transform; thread = (tile, channel), the 4 channels of an operand quad in adjacent lanes (16-byte rows of Vg)
+__global__ __launch_bounds__(256) void skp_wino4r_input_kernel(const float* __restrict__ x, float* __restrict__ Vg, int B, int Cin, int H,
+                                                               int W, int tilesX, int tilesPerImg, int nTiles, int vpad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int m = idx & 3, rest = idx >> 2;
+    const int tg = rest % vpad, q4 = rest / vpad;
+    if (q4 >= (Cin >> 2)) return;
+    const bool tv = tg < nTiles;
+    const int tgc = tv ? tg : 0;
+    const int b = tgc / tilesPerImg, rem = tgc - b * tilesPerImg;
+    const int ty = rem / tilesX, tx = rem - ty * tilesX;
+    const float dsc[6] = {0.25f, -1.f / 6, -1.f / 6, 1.f / 24, 1.f / 24, 1.f};
+    const float* xc = x + ((size_t)b * Cin + q4 * 4 + m) * H * W;
+    float d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = 4 * ty - 1 + i;
+        const bool rv = tv && r >= 0 && r < H;
+        const float* row = xc + r * W + 4 * tx;
+        const f32x4 mid = rv ? *(const f32x4*)row : f32x4{0.f, 0.f, 0.f, 0.f};
+        d[i][0] = (rv && tx > 0) ? row[-1] : 0.f;
+        d[i][1] = mid[0]; d[i][2] = mid[1]; d[i][3] = mid[2]; d[i][4] = mid[3];
+        d[i][5] = (rv && tx + 1 < tilesX) ? row[4] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float v[6], t[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = d[i][j];
+        w4_in1d(v, t);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i][j] = t[i];
+    }
+    const int c16 = q4 >> 2, kq = q4 & 3;
+    float* dst = Vg + (((size_t)c16 * 36 * 4 + kq) * vpad + tg) * 4 + m;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float t[6];
+        w4_in1d(d[i], t);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dst[(size_t)(i * 6 + j) * 16 * vpad] = t[j] * (dsc[i] * dsc[j]);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
+    extern __shared__ f32x4 vst[];                   // [2][36][4][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    int tblock, cg, zsplit;
+    if (!w4_work(a, blockIdx.x + blockIdx.z * gridDim.x, tblock, cg, zsplit)) return;
+    const int tile0 = tblock * 32;
+    const int n0 = (cg * 4 + wave) * 16;
+    const int HW = a.H * a.W;
+    const int nsteps = min(a.steps, a.total_steps - zsplit * a.steps);
+    const int c16_0 = zsplit * a.steps;
+    const i32x4 vrs = skp_make_rsrc(a.x, a.x_bytes);
+    const i32x4 wrs = skp_make_rsrc(a.U, a.u_bytes);
+
+    // transformed tiles of a stage -> LDS: f32x4 number r * 256 + tid of the stage image (row = 8 r + tid / 32 of its 144 (p, kq) rows)
+    const int v_vo = ((tid >> 5) * a.vpad + tile0 + (tid & 31)) * 16;
+    const int v_row8 = a.vpad * 128;                 // bytes between rows 8 apart
+    auto load_v = [&](int c16, int buf, int r) {
+        skp_buf_load_lds(vrs, (skp_lds_ptr)(vst + buf * W4_STAGE_F4 + r * 256 + wave * 64), 16, v_vo, c16 * 18 * v_row8 + r * v_row8, 0, 0);
+    };
+    // taps of the lane's four (cin, cout) pairs, one f32x4 (over cin % 4) per tap
+    const int CB = a.Cout >> 4;
+    const int w_cb = ((cg * 4 + wave) * 9) * 1024;
+    const int w_c16 = CB * 9 * 1024;
+    f32x4 g[9], gn[9];
+    auto load_g = [&](f32x4 (&dst)[9], int c16) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dst[t] = skp_buf_load_f32x4(wrs, lane * 16, c16 * w_c16 + w_cb + t * 1024, 0);
+    };
+    // row i of G' g G'^T: first the three column combinations of row i, then the six row combinations
+    auto u_row = [&](const f32x4 (&gg)[9], int i, f32x4 (&u)[6]) {
+        f32x4 t[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const f32x4 g0 = gg[b], g1 = gg[3 + b], g2 = gg[6 + b];
+            t[b] = i == 0 ? g0 : i == 5 ? g2 : i == 1 ? (g0 + g2) + g1 : i == 2 ? (g0 + g2) - g1
+                 : i == 3 ? (g0 + 4.f * g2) + 2.f * g1 : (g0 + 4.f * g2) - 2.f * g1;
+        }
+        const f32x4 s = t[0] + t[2], e = t[0] + 4.f * t[2], f = 2.f * t[1];
+        u[0] = t[0]; u[1] = s + t[1]; u[2] = s - t[1]; u[3] = e + f; u[4] = e - f; u[5] = t[2];
+    };
+
+    f32x4 acc[36][2];
+#pragma unroll
+    for (int p = 0; p < 36; ++p)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- output role (lane = tile within a 16-block, registers = 4 output channels) ----
+    int o_base[2];
+    bool t_ok[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tg = tile0 + tb * 16 + i16;
+        t_ok[tb] = tg < a.nTiles;
+        const int tgc = t_ok[tb] ? tg : 0;
+        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        o_base[tb] = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
+    }
+
+    // prologue: stage 0 tiles and taps
+#pragma unroll
+    for (int r = 0; r < 18; ++r) load_v(c16_0, 0, r);
+    load_g(g, c16_0);
+    f32x4 ur[2][6];
+    u_row(g, 0, ur[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // MODE 0: a further stage follows (its tiles and taps are requested on the side); MODE 1: last stage
+    auto run_stage = [&](int s, auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const f32x4* vb = vst + (s & 1) * W4_STAGE_F4 + kq * 32 + i16;
+        f32x4 va[3][2];
+        va[0][0] = vb[0];
+        va[0][1] = vb[16];
+        va[1][0] = vb[128];
+        va[1][1] = vb[128 + 16];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) {
+            const int i = p / 6, j = p - 6 * i;
+            if (MODE == 0) {                         // the taps first: they come from HBM, the tiles (L2 / MALL) queue behind them
+                if (p == 0) load_g(gn, c16_0 + s + 1);
+                else if (p <= 18) load_v(c16_0 + s + 1, (s + 1) & 1, p - 1);
+            }
+            if (j == 0 && i < 5) u_row(g, i + 1, ur[(i + 1) & 1]);
+            if (p + 2 < 36) {
+                va[(p + 2) % 3][0] = vb[(p + 2) * 128];
+                va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[i & 1][j][m], va[p % 3][tb][m], acc[p][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) g[t] = gn[t];
+            u_row(g, 0, ur[0]);
+        }
+    };
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        run_stage(s, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the LDS DMA of the next stage's tiles has landed
+        __syncthreads();
+    }
+    run_stage(nsteps - 1, std::integral_constant<int, 1>{});
+
+    // ---- output transform (in-lane) + store, as skp_wino4_conv_kernel ----
+    const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
+    const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
+    const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+    f32x4 rr[4][2][4];
+    float bvs[4];
+    auto load_res = [&](int r) {
+        const int co = n0 + 4 * kq + r;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const bool ok = t_ok[tb] && co < a.Cout;
+            const int vo = (o_base[tb] + co * HW) * 4;
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) rr[r][tb][oy] = skp_buf_load_f32x4(rrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 4 * kq + r;
+        bvs[r] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
+    }
+    load_res(0);
+    load_res(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = n0 + 4 * kq + r;
+        const float bv = bvs[r];
+        if (r + 2 < 4) load_res(r + 2);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const bool ok = t_ok[tb] && co < a.Cout;
+            const int vo = (o_base[tb] + co * HW) * 4;
+            float t[6][4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float m[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                w4_out1d(m, t[i]);
+            }
+#pragma unroll
+            for (int ox = 0; ox < 4; ++ox) {
+                float m[6], yv[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
+                w4_out1d(m, yv);
+#pragma unroll
+                for (int oy = 0; oy < 4; ++oy) rr[r][tb][oy][ox] += yv[oy] + bv;
+            }
+#pragma unroll
+            for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -732,6 +973,66 @@ int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     return best;
 }
 
+// ---- raw-filter form: geometry (always 64 channels x 32 tiles), K-split plan, gate ----
+static Wino4Grid wino4r_grid(int Cout, int tiles, int S) {
+    Wino4Grid g;
+    g.ntb = (tiles + 31) / 32;
+    g.ncg = Cout / 64;
+    g.tb_per_xcd = g.ntb >= 32 ? (g.ntb + 7) / 8 : 0;
+    if (g.tb_per_xcd) {
+        g.gx = 8u * g.tb_per_xcd * g.ncg;
+        g.rounds = (int)((g.gx * (unsigned)S + 255) / 256);
+    } else {
+        const int upx = (g.ncg * S + 7) / 8;
+        g.gx = 8u * upx * g.ntb;
+        g.rounds = (upx * g.ntb + 31) / 32;
+    }
+    return g;
+}
+// Where the form pays (tools/conv_raw_bench.py, profiles/r04_conv_raw.md): at most 128 tiles with >= 1280 channels on both sides
+// (the UNet's 8^2 and 16^2 levels at 8 rows: -14 .. -18 %), and up to 512 tiles when one side has >= 1920 channels (the 32^2
+// skip-connection layers: -7 %); the 640-channel layers stay on the transformed-filter kernels (equal or faster there).
+// SKP_WINO_RAW_MAX_TILES=<n>: every qualifying shape up to n tiles (experiments).
+static int wino4r_max_tiles() {
+    static const int v = [] { const char* e = getenv("SKP_WINO_RAW_MAX_TILES"); return e ? atoi(e) : 0; }();
+    return v;
+}
+static bool wino4r_layout_ok(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
+    if ((Cin % 16) || (Cout % 64) || (H % 4) || (W % 4)) return false;
+    const long long tiles = (long long)B * (H / 4) * (W / 4);
+    const long long vpad = (tiles + 31) / 32 * 32;
+    return 36ll * Cin * vpad * 4 < 0x7fffffffll && 9ll * Cin * Cout * 4 < 0x7fffffffll && (long long)B * Cout * H * W * 4 < 0x7fffffffll;
+}
+static bool wino4r_shape_ok(int B, int Cin, int Cout, int H, int W) {
+    if (!wino4r_layout_ok(B, Cin, Cout, H, W)) return false;
+    const long long tiles = (long long)B * (H / 4) * (W / 4);
+    if (wino4r_max_tiles() > 0) return tiles <= wino4r_max_tiles() && Cin >= 256;
+    if (tiles <= 128) return Cin >= 1280 && Cout >= 1280;
+    return tiles <= 512 && (Cin >= 1920 || Cout >= 1920) && Cin >= 640 && Cout >= 640;
+}
+static int wino4r_plan(int B, int Cin, int Cout, int H, int W) {
+    const int tiles = B * (H / 4) * (W / 4);
+    const int nsteps = Cin / 16;
+    const double out_bytes = (double)B * Cout * H * W * 4;
+    if (const char* e = getenv("SKP_WINO_SPLIT")) {
+        const int S = atoi(e);
+        if (S >= 1 && S <= 16 && (S - 1) * ((nsteps + S - 1) / S) < nsteps) return S;
+    }
+    int best = 1;
+    double best_cost = 1e30;
+    const double stage_us = 4.9;
+    for (int S = 1; S <= 16; ++S) {
+        const int per = (nsteps + S - 1) / S;
+        if ((S - 1) * per >= nsteps) continue;
+        const Wino4Grid g = wino4r_grid(Cout, tiles, S);
+        double cost = g.rounds * (per + 2.0) * stage_us;
+        if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
+        if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
+    }
+    return best;
+}
+
 }  // namespace
 
 extern "C" int skp_conv3x3_f4_filter_f32(const void* w, void* U, int Cout, int Cin, int flip_transpose, void* stream) {
@@ -866,6 +1167,83 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     if (rc || S == 1) return rc;
     const size_t n4 = out_elems / 4;
     hipLaunchKernelGGL(skp_wino4_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                       (const float*)bias, (const float*)residual, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
+    return skp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Raw-filter form (small-spatial layers): see skp_wino4r_conv_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int skp_conv3x3_f4r_ok(int B, int Cin, int Cout, int H, int W) {
+    static const bool on = [] { const char* e = getenv("SKP_WINO_RAW"); return !(e && e[0] == '0'); }();
+    return (on && wino4r_shape_ok(B, Cin, Cout, H, W)) ? 1 : 0;
+}
+
+// R: 9 * Cin * Cout floats.  flip_transpose as skp_conv3x3_f4_filter_f32 (the backward-data filter of w[Cin][Cout][3][3]).
+extern "C" int skp_conv3x3_f4r_filter_f32(const void* w, void* R, int Cout, int Cin, int flip_transpose, void* stream) {
+    if (!w || !R || Cout <= 0 || Cin <= 0) return SKP_E_BADARG;
+    if ((Cin & 15) || (Cout & 15)) return SKP_E_RANGE;
+    const int n = Cout * Cin;
+    hipLaunchKernelGGL(skp_wino4r_filter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w,
+                       (float*)R, Cout, Cin, flip_transpose);
+    return skp_launch_status();
+}
+
+// bytes: the pre-transformed input (36 * Cin * padded tiles floats) followed by the K-split partial outputs
+extern "C" int64_t skp_conv3x3_f4r_workspace(int B, int Cin, int Cout, int H, int W) {
+    if (!wino4r_layout_ok(B, Cin, Cout, H, W)) return 0;
+    const int64_t tiles = (int64_t)B * (H / 4) * (W / 4), vpad = (tiles + 31) / 32 * 32;
+    const int S = wino4r_plan(B, Cin, Cout, H, W);
+    return 36 * (int64_t)Cin * vpad * 4 + (S > 1 ? (int64_t)S * B * Cout * H * W * 4 : 0);
+}
+
+extern "C" int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bias, const void* residual, void* y, void* workspace,
+                                   int B, int Cin, int Cout, int H, int W, void* stream) {
+    if (!x || !R || !y || !workspace) return SKP_E_BADARG;
+    if (!wino4r_layout_ok(B, Cin, Cout, H, W)) return (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) ? SKP_E_BADARG : SKP_E_RANGE;
+    const int S = wino4r_plan(B, Cin, Cout, H, W);
+    Wino4Args a;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.tilesX = W / 4;
+    a.tilesPerImg = a.tilesX * (H / 4);
+    a.nTiles = B * a.tilesPerImg;
+    a.vpad = (a.nTiles + 31) / 32 * 32;
+    const size_t v_elems = (size_t)36 * Cin * a.vpad;
+    float* Vg = (float*)workspace;
+    float* part = Vg + v_elems;
+    a.x = Vg; a.U = (const float*)R;
+    a.x_bytes = (unsigned)(v_elems * 4); a.u_bytes = (unsigned)((size_t)9 * Cin * Cout * 4);
+    const size_t out_elems = (size_t)B * Cout * H * W;
+    a.y_bytes = (unsigned)(out_elems * 4);
+    a.total_steps = Cin / 16;
+    a.steps = (a.total_steps + S - 1) / S;
+    a.splits = S;
+    a.y_split_stride = out_elems;
+    a.y = S > 1 ? part : (float*)y;
+    a.bias = S > 1 ? nullptr : (const float*)bias;
+    a.res = S > 1 ? nullptr : (const float*)residual;
+    a.stats = nullptr; a.sblk = 0; a.gncoef = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const Wino4Grid g = wino4r_grid(Cout, a.nTiles, S);
+    a.ntb = g.ntb; a.ncg = g.ncg; a.tb_per_xcd = g.tb_per_xcd;
+    a.gx = (int)g.gx;
+    a.vtotal = g.tb_per_xcd ? (int)g.gx * S : (int)g.gx;
+    const int nin = a.vpad * Cin;
+    hipLaunchKernelGGL(skp_wino4r_input_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, (const float*)x, Vg, B, Cin, H, W,
+                       a.tilesX, a.tilesPerImg, a.nTiles, a.vpad);
+    const dim3 grid = g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1);
+    hipLaunchKernelGGL(skp_wino4r_conv_kernel, grid, dim3(256), lds, st, a);
+    int rc = skp_launch_status();
+    if (rc || S == 1) return rc;
+    const size_t n4 = out_elems / 4;
+    hipLaunchKernelGGL(skp_wino4_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)part,
                        (const float*)bias, (const float*)residual, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
     return skp_launch_status();
 }

@@ -838,6 +838,41 @@ def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None, out=None, stats
     return y
 
 
+def _wino4r_filters(weight, backward):
+    """The 9 taps of a frozen weight in MFMA operand order for the raw-filter form (9*Cin*Cout floats), built once."""
+    key = "_skp_wino4r_bwd" if backward else "_skp_wino4r_fwd"
+    hit = getattr(weight, key, None)
+    tag = (weight._version, weight.data_ptr())
+    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
+        return hit[1]
+    w = _dev(weight.detach(), "weight")
+    co, ci = w.shape[:2]
+    R = torch.empty(9 * co * ci, device=w.device, dtype=torch.float32)
+    if backward:
+        N.check(N.lib().skp_conv3x3_f4r_filter_f32(w.data_ptr(), R.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_f4r_filter_f32")
+    else:
+        N.check(N.lib().skp_conv3x3_f4r_filter_f32(w.data_ptr(), R.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_f4r_filter_f32")
+    setattr(weight, key, (tag, R))
+    return R
+
+
+def _conv3x3_f4r_raw(x, R, bias, cout, residual=None, out=None):
+    """Small-spatial form (csrc/skp_conv_wino4.hip, skp_wino4r_*): raw taps + in-lane filter transform, input transform in the workspace."""
+    B, ci, H, W = x.shape
+    y = out if out is not None else torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    nbytes = N.lib().skp_conv3x3_f4r_workspace(B, ci, cout, H, W)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    N.check(N.lib().skp_conv3x3_f4r_f32(x.data_ptr(), R.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        residual.data_ptr() if residual is not None else None, y.data_ptr(), ws.data_ptr(),
+                                        B, ci, cout, H, W, _stream()), "skp_conv3x3_f4r_f32")
+    return y
+
+
+def conv3x3_f4r_ok(x_shape, cout) -> bool:
+    b, ci, h, w = (int(v) for v in x_shape)
+    return CONV3X3_MODE == "f4" and bool(N.lib().skp_conv3x3_f4r_ok(b, ci, int(cout), h, w))
+
+
 # "f4": Winograd F(4x4,3x3) where the shape allows (H, W % 4 == 0), F(2x2,3x3) otherwise; "f2": F(2x2,3x3) only;
 # "lib": library convolution everywhere (A/B runs and the consistency test).  Default f4.
 CONV3X3_MODE = os.environ.get("SKP_CONV3X3", "f4")
@@ -872,9 +907,11 @@ def conv3x3_stats_blocks(x_shape, w_shape) -> int:
 def _conv3x3_run(x, weight, backward, bias, residual, cout, stats=None):
     w_shape = (weight.shape[1], weight.shape[0], 3, 3) if backward else weight.shape
     f4 = conv3x3_f4_ok(x.shape, w_shape)
+    B, ci, H, W = x.shape
+    if f4 and stats is None and conv3x3_f4r_ok(x.shape, cout):          # small spatial size, many channels: raw-filter form
+        return _conv3x3_f4r_raw(x, _wino4r_filters(weight, backward), bias, cout, residual=residual)
     U = _wino4_filters(weight, backward) if f4 else _wino_filters(weight, backward)
     run = _conv3x3_f4_raw if f4 else _conv3x3_raw
-    B, ci, H, W = x.shape
     per_image = max(ci, cout) * H * W * 4
     chunk = max(1, (2 ** 31 - 1) // per_image)           # rows per launch under the kernels' 2 GiB addressing limit
     if stats is not None:

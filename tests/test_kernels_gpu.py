@@ -461,3 +461,44 @@ def test_winograd_conv3x3_batch_chunking_over_2gib(ops):
     for i in (0, 3, 4):
         yi = ops.conv3x3(x[i:i + 1].contiguous(), w, b)
         assert torch.equal(y[i:i + 1], yi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,ci,co,H,W,bias,res", [(8, 1280, 1280, 8, 8, True, True), (8, 640, 1280, 16, 16, False, False),
+                                                   (8, 2560, 1280, 8, 8, True, False), (2, 256, 64, 16, 16, True, True),
+                                                   (3, 320, 128, 8, 12, False, True), (1, 272, 192, 4, 4, True, False)])
+def test_raw_filter_winograd_small_layers_vs_fp64(ops, B, ci, co, H, W, bias, res):
+    """Small-spatial form of the 3x3 convolution (raw taps, G g G^T applied in the lanes, input transform in the workspace:
+    skp_conv3x3_f4r_f32) against fp64 conv2d: forward with bias / residual, the input gradient through the same kernel with
+    the rotated / transposed taps, K-split and unsplit plans, ragged tile blocks (12 and 1 tiles of 32) and a channel count
+    that is not a multiple of 64 on the reduction side.  Same tolerance as the other F(4x4,3x3) kernels; bit-reproducible."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    b = torch.randn(co, generator=g) if bias else None
+    r = torch.randn(B, co, H, W, generator=g) if res else None
+    gy = torch.randn(B, co, H, W, generator=g)
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, w.double(), None if b is None else b.double(), padding=1)
+    if r is not None:
+        ref = ref + r.double()
+    (ref * gy.double()).sum().backward()
+    lib = ops.N.lib()
+    assert lib.skp_conv3x3_f4r_workspace(B, ci, co, H, W) > 0                    # a layout the kernel runs
+    assert lib.skp_conv3x3_f4r_ok(B, ci, co, H, W) == (1 if min(ci, co) >= 1280 else 0)     # ... and where it is routed to
+    xg, wg = x.cuda(), w.cuda()
+    bg, rg = (None if b is None else b.cuda()), (None if r is None else r.cuda())
+    y = ops._conv3x3_f4r_raw(xg, ops._wino4r_filters(wg, False), bg, co, residual=rg)
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-4, atol=6e-5 * ref.abs().max().item())
+    assert torch.equal(ops._conv3x3_f4r_raw(xg, ops._wino4r_filters(wg, False), bg, co, residual=rg), y)
+    if ci % 64 == 0:                                             # the backward-data launch swaps the channel roles
+        dx = ops._conv3x3_f4r_raw(gy.cuda(), ops._wino4r_filters(wg, True), None, ci)
+        torch.testing.assert_close(dx.cpu().double(), xd.grad, rtol=1e-4, atol=6e-5 * xd.grad.abs().max().item())
+        # and through autograd (Conv3x3Fn routes both directions by shape)
+        xq = xg.clone().requires_grad_(True)
+        routed = lib.skp_conv3x3_f4r_ok(B, ci, co, H, W) == 1 and lib.skp_conv3x3_f4r_ok(B, co, ci, H, W) == 1
+        yq = ops.conv3x3_auto(xq, wg, bg, rg) if routed else None
+        if yq is not None:
+            torch.testing.assert_close(yq.detach(), y, rtol=0, atol=0)
+            (yq * gy.cuda()).sum().backward()
+            torch.testing.assert_close(xq.grad, dx, rtol=0, atol=0)

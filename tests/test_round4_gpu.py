@@ -353,3 +353,4 @@ def test_column_sweep_map_backward_vs_fp64_dense_and_sweep(case, monkeypatch, ro
         torch.testing.assert_close(dS[l][..., :T], dD[l][..., :T], rtol=1e-4, atol=2e-5 * scale)
         if dW is not None:
             torch.testing.assert_close(dS[l][..., :T], dW[l][..., :T], rtol=1e-4, atol=2e-5 * scale)
+
