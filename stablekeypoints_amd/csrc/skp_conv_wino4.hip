@@ -453,12 +453,22 @@ __global__ __launch_bounds__(256) void skp_wino4r_input_kernel(const float* __re
     }
 }
 
+#ifdef W4R_STAMPS                                   // lab builds only (tools/): cycle stamps of workgroups 0 and 100
+__device__ unsigned long long w4r_stamps[2][64];
+#define W4R_STAMP(k) do { if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && (k) < 64) w4r_stamps[blockIdx.x ? 1 : 0][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W4R_STAMP(k) do { } while (0)
+#endif
+// PART: the launch is K-split -- the output is a partial sum for skp_wino4_reduce_kernel (which adds bias / residual): the
+// epilogue carries no bias / residual prefetch (128 registers less across the last stage: nothing spilled).
+template <bool PART>
 __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     int tblock, cg, zsplit;
     if (!w4_work(a, blockIdx.x + blockIdx.z * gridDim.x, tblock, cg, zsplit)) return;
+    W4R_STAMP(0);
     const int tile0 = tblock * 32;
     const int n0 = (cg * 4 + wave) * 16;
     const int HW = a.H * a.W;
@@ -522,11 +532,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     u_row(g, 0, ur[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    W4R_STAMP(1);
 
-    // MODE 0: a further stage follows (its tiles and taps are requested on the side); MODE 1: last stage
-    auto run_stage = [&](int s, auto mode_c) {
-        constexpr int MODE = decltype(mode_c)::value;
+    // One code path for every stage (a second copy of the MFMA loop for the last stage cost spilled accumulators): the side
+    // requests of the last stage re-fetch that stage (clamped index; nothing reads them).
+    for (int s = 0; s < nsteps; ++s) {
         const f32x4* vb = vst + (s & 1) * W4_STAGE_F4 + kq * 32 + i16;
+        const int c16n = c16_0 + min(s + 1, nsteps - 1);
         f32x4 va[3][2];
         va[0][0] = vb[0];
         va[0][1] = vb[16];
@@ -535,10 +547,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
 #pragma unroll
         for (int p = 0; p < 36; ++p) {
             const int i = p / 6, j = p - 6 * i;
-            if (MODE == 0) {                         // the taps first: they come from HBM, the tiles (L2 / MALL) queue behind them
-                if (p == 0) load_g(gn, c16_0 + s + 1);
-                else if (p <= 18) load_v(c16_0 + s + 1, (s + 1) & 1, p - 1);
-            }
+            if (p == 0) load_g(gn, c16n);                // the taps first: they come from HBM, the tiles (L2 / MALL) queue behind them
+            else if (p <= 18) load_v(c16n, (s + 1) & 1, p - 1);
             if (j == 0 && i < 5) u_row(g, i + 1, ur[(i + 1) & 1]);
             if (p + 2 < 36) {
                 va[(p + 2) % 3][0] = vb[(p + 2) * 128];
@@ -551,21 +561,55 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
                     acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[i & 1][j][m], va[p % 3][tb][m], acc[p][tb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (MODE == 0) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) g[t] = gn[t];
-            u_row(g, 0, ur[0]);
-        }
-    };
-    for (int s = 0; s + 1 < nsteps; ++s) {
-        run_stage(s, std::integral_constant<int, 0>{});
+        for (int t = 0; t < 9; ++t) g[t] = gn[t];
+        u_row(g, 0, ur[0]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the LDS DMA of the next stage's tiles has landed
         __syncthreads();
+        W4R_STAMP(2 + s);
     }
-    run_stage(nsteps - 1, std::integral_constant<int, 1>{});
 
     // ---- output transform (in-lane) + store, as skp_wino4_conv_kernel ----
+    __builtin_amdgcn_sched_barrier(0);
     const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
+    if (PART) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = n0 + 4 * kq + r;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const bool ok = t_ok[tb] && co < a.Cout;
+                const int vo = (o_base[tb] + co * HW) * 4;
+                float t[6][4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    float m[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                    w4_out1d(m, t[i]);
+                }
+                f32x4 o[4];
+#pragma unroll
+                for (int ox = 0; ox < 4; ++ox) {
+                    float m[6], yv[4];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) m[i] = t[i][ox];
+                    w4_out1d(m, yv);
+#pragma unroll
+                    for (int oy = 0; oy < 4; ++oy) o[oy][ox] = yv[oy];
+                }
+#pragma unroll
+                for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(o[oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        W4R_STAMP(40);
+#ifdef W4R_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        W4R_STAMP(41);
+#endif
+        return;
+    }
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
     const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
     f32x4 rr[4][2][4];
@@ -586,13 +630,12 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
         bvs[r] = skp_buf_load_f32(brs, co < a.Cout ? co * 4 : SKP_OOB, 0, 0);
     }
     load_res(0);
-    load_res(1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = n0 + 4 * kq + r;
         const float bv = bvs[r];
-        if (r + 2 < 4) load_res(r + 2);
+        if (r + 1 < 4) load_res(r + 1);
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
             const bool ok = t_ok[tb] && co < a.Cout;
@@ -1021,14 +1064,15 @@ static int wino4r_plan(int B, int Cin, int Cout, int H, int W) {
     }
     int best = 1;
     double best_cost = 1e30;
-    const double stage_us = 4.9;
+    // measured (cycle stamps, W4R_STAMPS builds): 4.8 us per stage, ~2.1 us prologue + ~5.3 us epilogue + dispatch per workgroup
+    const double stage_us = 4.8;
     for (int S = 1; S <= 16; ++S) {
         const int per = (nsteps + S - 1) / S;
         if ((S - 1) * per >= nsteps) continue;
         const Wino4Grid g = wino4r_grid(Cout, tiles, S);
-        double cost = g.rounds * (per + 2.0) * stage_us;
+        double cost = g.rounds * (per + 2.5) * stage_us;
         if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
-        if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
+        if (cost < best_cost * (S > 1 ? 0.97 : 1.0)) { best_cost = cost; best = S; }
     }
     return best;
 }
@@ -1227,7 +1271,9 @@ extern "C" int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bia
     const size_t lds = (size_t)2 * W4_STAGE_F4 * sizeof(f32x4);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -1239,7 +1285,8 @@ extern "C" int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bia
     hipLaunchKernelGGL(skp_wino4r_input_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, (const float*)x, Vg, B, Cin, H, W,
                        a.tilesX, a.tilesPerImg, a.nTiles, a.vpad);
     const dim3 grid = g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1);
-    hipLaunchKernelGGL(skp_wino4r_conv_kernel, grid, dim3(256), lds, st, a);
+    if (S > 1) hipLaunchKernelGGL(skp_wino4r_conv_kernel<true>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(skp_wino4r_conv_kernel<false>, grid, dim3(256), lds, st, a);
     int rc = skp_launch_status();
     if (rc || S == 1) return rc;
     const size_t n4 = out_elems / 4;
@@ -1247,3 +1294,9 @@ extern "C" int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bia
                        (const float*)bias, (const float*)residual, (float*)y, n4, out_elems, S, (H * W) / 4, Cout);
     return skp_launch_status();
 }
+
+#ifdef W4R_STAMPS
+extern "C" int skp_w4r_read_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w4r_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
