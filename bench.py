@@ -264,12 +264,14 @@ def conv_step_forms(ops, B, image_size, iters, device):
 
 def conv_step_accounting(ops, one_step, log_path=None):
     """Every Winograd F(4x4,3x3) launch of ONE optimizer step (VAE encoder + UNet forward + UNet backward-data), timed with an
-    event pair on the launch stream around each C-ABI call (the K-split reduction of a split launch included), with its
+    event pair on the launch stream around each C-ABI call (the K-split reduction of a split launch and the input-transform
+    kernel of the raw-filter form included), with its
     algorithmic FLOPs = 2*9*Cin*Cout*B*H*W / 4: the TIME-WEIGHTED fraction of the fp32 matrix peak over all of them
     (sum of FLOPs / sum of time / 157.3) is the number the per-shape `roofline.frac` cannot give.  The launch list goes to
     `log_path` (tools/step_breakdown.py joins it with a rocprofv3 kernel trace by launch order)."""
     lib = ops.N.lib()
-    names = {"skp_conv3x3_f4_f32": 6, "skp_conv3x3_f4_stats_f32": 6, "skp_conv3x3_f4_gn_f32": 7}     # index of B in the arguments
+    names = {"skp_conv3x3_f4_f32": 6, "skp_conv3x3_f4_stats_f32": 6, "skp_conv3x3_f4_gn_f32": 7,
+             "skp_conv3x3_f4r_f32": 6}                                                          # index of B in the arguments
     real = {n: getattr(lib, n) for n in names}
     log = []
 
@@ -297,7 +299,8 @@ def conv_step_accounting(ops, one_step, log_path=None):
         us = e0.elapsed_time(e1) * 1e3
         fl = 2.0 * 9 * ci * co * B * H * W / 4
         rows.append({"entry": name, "B": B, "Cin": ci, "Cout": co, "H": H, "W": W, "algorithmic_flops": fl, "us": us})
-        d = by_shape.setdefault((name.replace("skp_conv3x3_f4_", "").replace("_f32", "") or "plain", ci, co, H, W, B), [0, 0.0, 0.0])
+        d = by_shape.setdefault((name.replace("skp_conv3x3_f4r_f32", "raw-filter").replace("skp_conv3x3_f4_", "").replace("_f32", "") or "plain",
+                                 ci, co, H, W, B), [0, 0.0, 0.0])
         d[0] += 1; d[1] += fl; d[2] += us
     if not rows:
         return None

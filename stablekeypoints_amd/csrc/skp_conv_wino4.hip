@@ -492,17 +492,31 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) dst[t] = skp_buf_load_f32x4(wrs, lane * 16, c16 * w_c16 + w_cb + t * 1024, 0);
     };
-    // row i of G' g G'^T: first the three column combinations of row i, then the six row combinations
-    auto u_row = [&](const f32x4 (&gg)[9], int i, f32x4 (&u)[6]) {
-        f32x4 t[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
+    // row i of G' g G'^T in six pieces (one per position of the previous row, so that a few VALU operations sit between the MFMAs
+    // of every position instead of forty in front of one): piece 0..2 = the column combination t[b] of row i, 3..5 = the row
+    // combinations (u[0] = t[0] and u[5] = t[2] are aliases)
+    f32x4 ut[3];
+    auto u_piece = [&](const f32x4 (&gg)[9], int i, int piece, f32x4 (&u)[6]) {
+        if (piece < 3) {
+            const int b = piece;
             const f32x4 g0 = gg[b], g1 = gg[3 + b], g2 = gg[6 + b];
-            t[b] = i == 0 ? g0 : i == 5 ? g2 : i == 1 ? (g0 + g2) + g1 : i == 2 ? (g0 + g2) - g1
-                 : i == 3 ? (g0 + 4.f * g2) + 2.f * g1 : (g0 + 4.f * g2) - 2.f * g1;
+            ut[b] = i == 0 ? g0 : i == 5 ? g2 : i == 1 ? (g0 + g2) + g1 : i == 2 ? (g0 + g2) - g1
+                  : i == 3 ? (g0 + 4.f * g2) + 2.f * g1 : (g0 + 4.f * g2) - 2.f * g1;
+        } else if (piece == 3) {
+            const f32x4 s2 = ut[0] + ut[2];
+            u[0] = ut[0]; u[5] = ut[2];
+            u[1] = s2 + ut[1]; u[2] = s2 - ut[1];
+        } else if (piece == 4) {
+            const f32x4 e = ut[0] + 4.f * ut[2];
+            u[3] = e + 2.f * ut[1];
+        } else {
+            const f32x4 e = ut[0] + 4.f * ut[2];
+            u[4] = e - 2.f * ut[1];
         }
-        const f32x4 s = t[0] + t[2], e = t[0] + 4.f * t[2], f = 2.f * t[1];
-        u[0] = t[0]; u[1] = s + t[1]; u[2] = s - t[1]; u[3] = e + f; u[4] = e - f; u[5] = t[2];
+    };
+    auto u_row = [&](const f32x4 (&gg)[9], int i, f32x4 (&u)[6]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) u_piece(gg, i, k, u);
     };
 
     f32x4 acc[36][2];
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     for (int s = 0; s < nsteps; ++s) {
         const f32x4* vb = vst + (s & 1) * W4_STAGE_F4 + kq * 32 + i16;
         const int c16n = c16_0 + min(s + 1, nsteps - 1);
-        f32x4 va[3][2];
+        f32x4 va[3][2];                              // LDS operands two positions ahead (three: measured no faster)
         va[0][0] = vb[0];
         va[0][1] = vb[16];
         va[1][0] = vb[128];
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
             const int i = p / 6, j = p - 6 * i;
             if (p == 0) load_g(gn, c16n);                // the taps first: they come from HBM, the tiles (L2 / MALL) queue behind them
             else if (p <= 18) load_v(c16n, (s + 1) & 1, p - 1);
-            if (j == 0 && i < 5) u_row(g, i + 1, ur[(i + 1) & 1]);
+            if (i < 5) u_piece(g, i + 1, j, ur[(i + 1) & 1]);
             if (p + 2 < 36) {
                 va[(p + 2) % 3][0] = vb[(p + 2) * 128];
                 va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];

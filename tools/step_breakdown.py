@@ -108,24 +108,30 @@ def conv_fraction(rows, bounds, nwin, conv_log):
     per = {}
     for k in range(nwin):
         lo, hi = bounds[-1 - nwin + k], bounds[-nwin + k]
-        win = [(st, en, short(name)) for st, en, name, _ in rows if st >= lo and en <= hi and "skp_wino4_" in name]
-        main = [w for w in win if "skp_wino4_conv" in w[2]]          # one per C-ABI call; reduce kernels only add time
+        win = [(st, en, short(name)) for st, en, name, _ in rows if st >= lo and en <= hi and ("skp_wino4_" in name or "skp_wino4r_" in name)]
+        is_main = lambda n: "skp_wino4_conv" in n or "skp_wino4r_conv" in n
+        main = [w for w in win if is_main(w[2])]                     # one per C-ABI call; reduce / input-transform kernels only add time
         if len(main) != len(conv_log):
             print(f"\nconv log has {len(conv_log)} launches, step {k} of the trace {len(main)}: not the same configuration")
             return
         tot_ns += sum(en - st for st, en, _ in win)
         tot_f += sum(l["algorithmic_flops"] for l in conv_log)
-        # attribute a reduce kernel to the conv launch in front of it
-        cur = None
+        # attribute a reduce kernel to the conv launch in front of it, the raw-filter form's input transform to the one behind it
+        cur, held = None, 0
         for st, en, name in win:
-            if "skp_wino4_conv" in name:
+            if "skp_wino4r_input" in name:
+                held += en - st
+                continue
+            if is_main(name):
                 cur = conv_log[main.index((st, en, name))]
-                key = (name.replace("skp_wino4_conv", ""), cur["Cin"], cur["Cout"], cur["H"], cur["W"], cur["B"])
+                key = (name.replace("skp_wino4_conv", "").replace("skp_wino4r_conv", "raw-filter"), cur["Cin"], cur["Cout"], cur["H"], cur["W"], cur["B"])
                 d = per.setdefault(key, [0, 0.0, 0.0])
                 d[0] += 1; d[1] += cur["algorithmic_flops"]
+                d[2] += held
+                held = 0
             if cur is not None:
                 per[key][2] += en - st
-    print(f"\nall skp_wino4_* kernels: {tot_f / nwin / 1e12:.3f} TFLOP executed (direct-form / 4) in {tot_ns / nwin / 1e6:.2f} ms per "
+    print(f"\nall skp_wino4_* / skp_wino4r_* kernels: {tot_f / nwin / 1e12:.3f} TFLOP executed (direct-form / 4) in {tot_ns / nwin / 1e6:.2f} ms per "
           f"step => {tot_f / tot_ns / 1e3:.1f} TF/s = {tot_f / tot_ns / 1e3 / F32_MATRIX_PEAK_TF:.3f} of the {F32_MATRIX_PEAK_TF} TF/s "
           "fp32 matrix peak (time-weighted over every launch)")
     print("| kernel form | Cin->Cout @ HxW, rows | calls/step | ms/step | frac |\n|---|---|---|---|---|")
