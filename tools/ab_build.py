@@ -6,7 +6,8 @@
 Each library is timed in its own subprocess (SKP_LIB_PATH), the builds alternate A B A B ... so that clock / thermal drift
 of the box does not land on one of them.  Shapes: `gn` = 128->128 @512^2 with GroupNorm folded + statistics (launches #0-#3 of
 a step), `plain` = the same without either, `s256` / `s128` / `s64` = the VAE's deeper levels with the statistics epilogue,
-`u320` = 320->320 @64^2, `u1280_16` / `u640_32` / `u1280_8` = K-split UNet layers."""
+`u320` = 320->320 @64^2, `u1280_16` / `u640_32` / `u1280_8` = K-split UNet layers, `r1280_8` / `r2560_8` / `r1280_16` /
+`r2560_16` = the raw-filter form at the 8^2 / 16^2 layers."""
 import argparse
 import json
 import os
@@ -17,7 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = {"gn": (8, 128, 128, 512, "gn"), "plain": (8, 128, 128, 512, "plain"), "s256": (8, 256, 256, 256, "stats"),
           "s128": (8, 512, 512, 128, "stats"), "s64": (8, 512, 512, 64, "stats"), "u320": (8, 320, 320, 64, "stats"),
           "u1280_16": (8, 1280, 1280, 16, "plain"), "u640_32": (8, 640, 640, 32, "plain"), "u1280_8": (8, 1280, 1280, 8, "plain"),
-          "u2560_16": (8, 2560, 1280, 16, "plain"), "u1920_32": (8, 1920, 640, 32, "plain")}
+          "u2560_16": (8, 2560, 1280, 16, "plain"), "u1920_32": (8, 1920, 640, 32, "plain"),
+          # the raw-filter form (skp_conv3x3_f4r_f32: input transform + convolution + K-split reduction per call)
+          "r1280_8": (8, 1280, 1280, 8, "raw"), "r2560_8": (8, 2560, 1280, 8, "raw"), "r1280_16": (8, 1280, 1280, 16, "raw"),
+          "r2560_16": (8, 2560, 1280, 16, "raw")}
 
 
 def worker(names, iters):
@@ -31,10 +35,12 @@ def worker(names, iters):
         B, ci, co, sz, form = SHAPES[name]
         x = torch.randn(B, ci, sz, sz, generator=g).cuda()
         w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
-        U = ops._wino4_filters(w, False)
         y = torch.empty(B, co, sz, sz, device="cuda")
+        U = ops._wino4r_filters(w, False) if form == "raw" else ops._wino4_filters(w, False)
         nblk = ops.conv3x3_stats_blocks(x.shape, w.shape)
-        if form == "gn":
+        if form == "raw":
+            fn = lambda: ops._conv3x3_f4r_raw(x, U, None, co, out=y)
+        elif form == "gn":
             stats = torch.empty(B, co, nblk, 2, device="cuda")
             coef = torch.stack([torch.full((B, ci), 0.7), torch.full((B, ci), 0.1)], dim=-1).cuda().contiguous()
             fn = lambda: N.check(lib.skp_conv3x3_f4_gn_f32(x.data_ptr(), U.data_ptr(), None, None, y.data_ptr(), stats.data_ptr(),

@@ -27,7 +27,8 @@ python - "$OUT" $SHAPES <<'PY'
 import json, sys, os
 out, shapes = sys.argv[1], sys.argv[2:]
 SH = {"gn": (8, 128, 128, 512), "plain": (8, 128, 128, 512), "s256": (8, 256, 256, 256), "s128": (8, 512, 512, 128), "s64": (8, 512, 512, 64),
-      "u320": (8, 320, 320, 64), "u1280_16": (8, 1280, 1280, 16), "u640_32": (8, 640, 640, 32), "u1280_8": (8, 1280, 1280, 8)}
+      "u320": (8, 320, 320, 64), "u1280_16": (8, 1280, 1280, 16), "u640_32": (8, 640, 640, 32), "u1280_8": (8, 1280, 1280, 8),
+      "r1280_8": (8, 1280, 1280, 8), "r2560_8": (8, 2560, 1280, 8), "r1280_16": (8, 1280, 1280, 16), "r2560_16": (8, 2560, 1280, 16)}
 lines = ["| shape | kernel | MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)) | HBM-side bytes / launch (2 x FETCH + WRITE) | algorithmic bytes | ratio |", "|---|---|---|---|---|---|"]
 for s in shapes:
     try:
@@ -35,9 +36,10 @@ for s in shapes:
     except Exception as e:
         lines.append(f"| {s} | (no data: {e}) | | | | |"); continue
     B, ci, co, sz = SH[s]
-    alg = 4 * (B * ci * sz * sz + B * co * sz * sz + 36 * ci * co)
+    raw = s.startswith("r")                      # raw-filter form: 9 taps instead of 36 transformed values (+ its helper kernels' rows)
+    alg = 4 * (B * ci * sz * sz + B * co * sz * sz + (9 if raw else 36) * ci * co)
     for name, c in k.items():
-        if "skp_wino4_conv" not in name:
+        if "skp_wino4_conv" not in name and "skp_wino4r_" not in name and not (raw and "skp_wino4_reduce" in name):
             continue
         busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1.0, 4 * c.get("SQ_BUSY_CU_CYCLES", 0)) if "SQ_BUSY_CU_CYCLES" in c else float("nan")
         tr = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
