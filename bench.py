@@ -371,7 +371,7 @@ def cpu_baseline(ldm_cpu, args):
             "thread_sweep_256_images_per_sec": {str(k): v for k, v in sweep.items()}}
 
 
-def measured_traffic(kernel_substr):
+def measured_traffic(kernel_substr, template=None):
     """(HBM bytes per launch, source file) of a kernel from the committed rocprofv3 --pmc passes (profiles/*.json: separate
     FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at the same launch shape, FETCH_SIZE doubled per
     MI355X_MICROARCH.md 'HBM'; regenerate with tools/pmc_traffic.sh).  (None, None) when no profile is present."""
@@ -384,6 +384,8 @@ def measured_traffic(kernel_substr):
             continue
         for name, c in k.items():
             plain = re.sub(r"<[^<>]*>", "", name).replace("void ", "")          # template arguments / return type of the trace name
+            if template is not None and f"<{template}>" not in name.replace(" ", ""):      # the persistent conv kernel: one grid, several forms
+                continue
             if kernel_substr in plain and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), "profiles/" + os.path.basename(path)
     return None, None
@@ -634,11 +636,12 @@ def main():
         except Exception as e:                                    # noqa: BLE001 -- the line of record does not depend on the probe
             print(f"bench.py: MFMA issue-rate probe unavailable ({e})", file=sys.stderr)
             issue1 = issue2 = None
-        conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}")
+        conv_traffic, conv_src = measured_traffic(f"skp_wino4_conv_c128_kernel@grid{cv_grid}",
+                                                  template="true,true" if cv_folded else "false,false")
         if conv_traffic is None:                                 # committed passes from before the kernel became persistent: same
             conv_traffic, conv_src = measured_traffic("skp_wino4_conv_c128_kernel@grid2097152")    # launch shape, one workgroup per unit
         map_kernel = "skp_attn_map_fwd_wide_kernel" if ops.map_wide_supported(a.tokens, a.res) else "skp_attn_map_fwd_kernel"
-        map_traffic, map_src = measured_traffic(map_kernel)
+        map_traffic, map_src = measured_traffic(map_kernel, template=None if "wide" in map_kernel else f"{(a.tokens + 15) // 16 * 16},0")
         live, map_bwd_traffic = None, None
         if a.traffic == "live" or (a.traffic == "auto" and world == 1 and a.model == "sd15"):
             torch.cuda.empty_cache()
