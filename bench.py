@@ -299,8 +299,9 @@ def conv_step_accounting(ops, one_step, log_path=None):
         us = e0.elapsed_time(e1) * 1e3
         fl = 2.0 * 9 * ci * co * B * H * W / 4
         rows.append({"entry": name, "B": B, "Cin": ci, "Cout": co, "H": H, "W": W, "algorithmic_flops": fl, "us": us})
-        d = by_shape.setdefault((name.replace("skp_conv3x3_f4r_f32", "raw-filter").replace("skp_conv3x3_f4_", "").replace("_f32", "") or "plain",
-                                 ci, co, H, W, B), [0, 0.0, 0.0])
+        form = {"skp_conv3x3_f4_f32": "plain", "skp_conv3x3_f4_stats_f32": "stats", "skp_conv3x3_f4_gn_f32": "gn",
+                "skp_conv3x3_f4r_f32": "raw-filter"}[name]
+        d = by_shape.setdefault((form, ci, co, H, W, B), [0, 0.0, 0.0])
         d[0] += 1; d[1] += fl; d[2] += us
     if not rows:
         return None
