@@ -161,7 +161,7 @@ int skp_conv3x3_f4_gn_f32(const void* x, const void* U, const void* bias, const 
  * (skp_conv3x3_f4r_filter_f32: R, 9 * Cin * Cout floats, in MFMA operand order; flip_transpose as above), G g G^T is applied
  * by the lanes on the way into the matrix cores, and the input transform runs once per launch into the workspace.
  * Shapes the kernel RUNS: Cin % 16 == 0, Cout % 64 == 0, H, W % 4 == 0 (else SKP_E_RANGE).  skp_conv3x3_f4r_ok: 1 where
- * it also PAYS against the kernels above (measured: <= 128 tiles with >= 1280 channels on both sides, <= 512 tiles with
+ * it also PAYS against the kernels above (measured: >= 1280 channels on both sides up to 1536 tiles, <= 512 tiles with
  * >= 1920 on one; SKP_WINO_RAW=0 turns it off) -- the rule the Python layer routes by.  workspace:
  * skp_conv3x3_f4r_workspace() bytes, REQUIRED (pre-transformed input + K-split partials).  fp32, fixed K-split order
  * (bit-reproducible). */

@@ -1046,9 +1046,10 @@ static Wino4Grid wino4r_grid(int Cout, int tiles, int S) {
     }
     return g;
 }
-// Where the form pays (tools/conv_raw_bench.py, profiles/r04_conv_raw.md): at most 128 tiles with >= 1280 channels on both sides
-// (the UNet's 8^2 and 16^2 levels at 8 rows: -14 .. -18 %), and up to 512 tiles when one side has >= 1920 channels (the 32^2
-// skip-connection layers: -7 %); the 640-channel layers stay on the transformed-filter kernels (equal or faster there).
+// Where the form pays (tools/conv_raw_bench.py, profiles/r04_conv_raw.md): >= 1280 channels on both sides at up to 1536 tiles
+// (the UNet's 8^2 / 16^2 levels and 1280 -> 1280 at 32^2, measured at 4 .. 40 rows: -12 .. -26 %), and up to 512 tiles when one
+// side has >= 1920 channels (the 32^2 skip-connection layers: -7 %); the 640-channel layers stay on the transformed-filter
+// kernels (equal or faster there at the step's 8 rows).
 // SKP_WINO_RAW_MAX_TILES=<n>: every qualifying shape up to n tiles (experiments).
 static int wino4r_max_tiles() {
     static const int v = [] { const char* e = getenv("SKP_WINO_RAW_MAX_TILES"); return e ? atoi(e) : 0; }();
@@ -1065,7 +1066,7 @@ static bool wino4r_shape_ok(int B, int Cin, int Cout, int H, int W) {
     if (!wino4r_layout_ok(B, Cin, Cout, H, W)) return false;
     const long long tiles = (long long)B * (H / 4) * (W / 4);
     if (wino4r_max_tiles() > 0) return tiles <= wino4r_max_tiles() && Cin >= 256;
-    if (tiles <= 128) return Cin >= 1280 && Cout >= 1280;
+    if (Cin >= 1280 && Cout >= 1280) return tiles <= 1536;
     return tiles <= 512 && (Cin >= 1920 || Cout >= 1920) && Cin >= 640 && Cout >= 640;
 }
 static int wino4r_plan(int B, int Cin, int Cout, int H, int W) {

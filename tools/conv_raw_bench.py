@@ -13,7 +13,7 @@ from stablekeypoints_amd import ops  # noqa: E402
 
 SHAPES = [(8, 1280, 1280, 8), (8, 2560, 1280, 8), (8, 1280, 2560, 8), (8, 1280, 1280, 16), (8, 2560, 1280, 16), (8, 1280, 2560, 16),
           (8, 1920, 1280, 16), (8, 1280, 1920, 16), (8, 640, 1280, 16), (8, 1280, 640, 16),
-          (8, 640, 640, 32), (8, 1280, 640, 32), (8, 1920, 640, 32), (8, 640, 1920, 32), (8, 960, 640, 32)]
+          (8, 640, 640, 32), (8, 1280, 1280, 32), (8, 1280, 640, 32), (8, 1920, 640, 32), (8, 640, 1920, 32), (8, 960, 640, 32)]
 
 
 def timed(fn, iters):
@@ -30,6 +30,7 @@ def timed(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=0, help="batch rows instead of the step's 8 (the augmented inference runs 10 / 20 / 40)")
     a = ap.parse_args()
     g = torch.Generator().manual_seed(0)
     lib = ops.N.lib()
@@ -39,6 +40,7 @@ def main():
     for B, ci, co, s in SHAPES:
         if only and only not in f"{ci}->{co} @{s}^2":
             continue
+        B = a.rows or B
         x = torch.randn(B, ci, s, s, generator=g).cuda()
         w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
         U = ops._wino4_filters(w, False)
