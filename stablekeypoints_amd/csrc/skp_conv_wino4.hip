@@ -10,6 +10,8 @@
 //   * skp_wino4_conv_c128_kernel: wave = 32 output channels x 16 tiles x 36 positions, workgroup = 128 channels x 16 tiles
 //     (>= 128 tiles, Cout a multiple of 128 or its last group >= 64): half the input-transform work per MFMA, two filter
 //     loads per position.
+//   * skp_wino4r_conv_kernel:     the first form's tile with the filter kept as its 9 taps and transformed in the lanes, the input
+//     transformed once per launch by its own kernel (small-spatial layers with >= 1280 channels: see the section further down)
 // The workgroup transforms the input patches of a 16-channel stage into LDS once (double buffered, 2 x 72 / 36 KB) in
 // MFMA operand order.  The transformed filter is streamed from L2 through a register ring (12 / 6 positions deep; VMEM
 // returns in order: everything queued behind a patch load inherits its latency, so the ring has to cover it).  The
@@ -460,7 +462,7 @@ __device__ unsigned long long w4r_stamps[2][64];
 #define W4R_STAMP(k) do { } while (0)
 #endif
 // PART: the launch is K-split -- the output is a partial sum for skp_wino4_reduce_kernel (which adds bias / residual): the
-// epilogue carries no bias / residual prefetch (128 registers less across the last stage: nothing spilled).
+// epilogue carries no bias / residual prefetch (128 registers less at the end of the stage loop).
 template <bool PART>
 __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]

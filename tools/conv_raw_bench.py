@@ -13,7 +13,8 @@ from stablekeypoints_amd import ops  # noqa: E402
 
 SHAPES = [(8, 1280, 1280, 8), (8, 2560, 1280, 8), (8, 1280, 2560, 8), (8, 1280, 1280, 16), (8, 2560, 1280, 16), (8, 1280, 2560, 16),
           (8, 1920, 1280, 16), (8, 1280, 1920, 16), (8, 640, 1280, 16), (8, 1280, 640, 16),
-          (8, 640, 640, 32), (8, 1280, 1280, 32), (8, 1280, 640, 32), (8, 1920, 640, 32), (8, 640, 1920, 32), (8, 960, 640, 32)]
+          (8, 640, 640, 32), (8, 1280, 1280, 32), (8, 1280, 640, 32), (8, 1920, 640, 32), (8, 640, 1920, 32), (8, 960, 640, 32),
+          (8, 512, 512, 64), (8, 320, 320, 64), (8, 640, 320, 64), (8, 960, 320, 64)]        # far outside the gate (SKP_WINO_RAW_MAX_TILES=4096)
 
 
 def timed(fn, iters):
