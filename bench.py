@@ -504,8 +504,27 @@ def rccl_self_check(D, world, rank, dev):
     return {"backend": torch.distributed.get_backend(), "ok": True, "ranks_seen": int(v[:world].sum().item())}
 
 
+def self_launch_command(gpus, argv, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: the command that re-runs this file under
+    `torch.distributed.run`, one rank per GPU on 127.0.0.1 (the driver's own N > 1 command line, verbatim)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:                               # a port the kernel says is free right now
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun around us: become the launcher (exit status = torchrun's: non-zero if any rank dies; rank 0 of
+        # the relaunched job prints the one JSON line on the inherited stdout)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC is the only form the host driver supports
+        cmd = self_launch_command(a.gpus, sys.argv[1:])
+        print("bench.py: --gpus %d without a launcher environment -> %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     from stablekeypoints_amd import dist as D
     world, rank, local = D.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"

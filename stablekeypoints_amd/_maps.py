@@ -50,6 +50,15 @@ class FusedAttn:
         run per head (ops.materialize_probs); host tensors (the module tree on CPU, which is what the build container and
         oracle/ can drive): the same quantity in torch ops -- softmax_t(bicubic_R(scale q k^T))."""
         if self._mat is None:
+            if torch.is_grad_enabled() and (self.q.requires_grad or self.k.requires_grad):
+                raise RuntimeError(
+                    "FusedAttn: a stored cross-attention handle was turned into the reference's (B*h, R^2, T) tensor while "
+                    "autograd is recording and its q / k carry gradient history.  The materialised tensor is a compatibility "
+                    "view WITHOUT autograd, so a loss built on it cannot reach the embedding (`loss.backward()` would fail "
+                    "with 'does not require grad').  This happens when only `optimize_token.load_ldm` was re-bound and the "
+                    "reference's own `optimize.optimize_embedding` / `optimize.collect_maps` still run the training loop: "
+                    "re-bind `optimize.optimize_embedding` (or at least `optimize.collect_maps`) to stablekeypoints_amd.optimize "
+                    "as well (INTEGRATION.md section A, stage 1), or wrap inference-only callers in torch.no_grad().")
             q, k = self.q.detach(), self.k.detach()
             if q.is_cuda:
                 self._mat = ops.materialize_probs(q, k, self.heads, self.scale, self.R)
@@ -58,10 +67,34 @@ class FusedAttn:
         return self._mat
 
     # ---- tensor duck typing (see the class docstring) ----
+    # what reference-order code calls on a stored entry (optimize.py:52-75, eval.py, visualize.py) plus the usual
+    # conversions; anything else (a typo, a hasattr() probe) must NOT silently build the 161 MB tensor
+    _FORWARDED = frozenset((
+        "reshape", "view", "permute", "transpose", "flatten", "unsqueeze", "squeeze", "contiguous", "clone", "detach",
+        "mean", "sum", "max", "min", "argmax", "softmax", "float", "double", "half", "to", "cpu", "cuda", "numpy", "tolist",
+        "type", "chunk", "split", "unbind", "index_select", "T", "mT", "abs", "mul", "add", "div", "sub", "expand",
+        "repeat", "narrow", "select", "amax", "amin", "topk", "sort", "isfinite", "isnan", "all", "any", "item"))
+
+    @property
+    def ndim(self):
+        return 3
+
+    @property
+    def is_cuda(self):
+        return self.q.is_cuda
+
+    @property
+    def requires_grad(self):
+        return False                                             # of the materialised view (see materialize())
+
+    def numel(self):
+        return self.shape.numel()
+
     def __getattr__(self, name):
-        if name.startswith("__") or name in FusedAttn.__slots__:
-            raise AttributeError(name)
-        return getattr(self.materialize(), name)
+        if name in FusedAttn._FORWARDED:
+            return getattr(self.materialize(), name)
+        raise AttributeError(f"FusedAttn has no attribute '{name}' (tensor methods forwarded to the materialised "
+                             f"(B*h, R^2, T) view: {', '.join(sorted(FusedAttn._FORWARDED))})")
 
     def __getitem__(self, idx):
         return self.materialize()[idx]
@@ -74,8 +107,8 @@ class FusedAttn:
         def conv(a):
             if isinstance(a, FusedAttn):
                 return a.materialize()
-            if isinstance(a, (list, tuple)):
-                return type(a)(conv(v) for v in a)
+            if isinstance(a, (list, tuple)):                     # rebuilt as plain list / tuple (a namedtuple's constructor
+                return (list if isinstance(a, list) else tuple)(conv(v) for v in a)   # does not take a generator)
             return a
         return func(*conv(args), **{k_: conv(v) for k_, v in (kwargs or {}).items()})
 

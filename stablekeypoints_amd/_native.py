@@ -121,7 +121,8 @@ def lib():
 
 # measurement aids / experiments live in their own library (tools/csrc -> libskp_lab.so, tools/csrc/skp_lab.h); the product
 # library does not contain them
-LAB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "csrc", "libskp_lab.so")
+# (SKP_LAB_PATH overrides the in-checkout location, e.g. when the package is installed outside the repository tree)
+LAB_PATH = os.environ.get("SKP_LAB_PATH") or os.path.join(os.path.dirname(_HERE), "tools", "csrc", "libskp_lab.so")
 LAB_SIGNATURES = {
     "skp_probe_mfma_f32": [_i, _i, _vp, _vp, _vp],
     "skp_gemm_x3_split_f32": [_vp, _vp, _i, _i, _i, _vp],

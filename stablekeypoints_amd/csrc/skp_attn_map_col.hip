@@ -98,9 +98,10 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
     const int k0 = ch * CL_TC;                   // SEL: first selected slot; natural: first token
 
     float* Vg = smem;                            // [2][K2*s][CL_TS]
-    float* xb = smem + 2 * VG;                   // [2][R*E + 1][CL_PS]
-    float* tabw = xb + 2 * XB;                   // [R][4] vertical tap weights of every up-res row
-    int* lst = (int*)(tabw + R * 4);             // [s][CL_LUSE]
+    float* tabw = smem + 2 * VG;                 // [R][4] vertical tap weights of every up-res row, read as f32x4: it sits
+    static_assert((2 * VG) % 4 == 0, "tabw must start on a 16-byte boundary (ds_read_b128)");   // BEFORE the odd-sized xb
+    float* xb = tabw + R * 4;                    // [2][R*E + 1][CL_PS]
+    int* lst = (int*)(xb + 2 * XB);              // [s][CL_LUSE]
     int* selk = lst + s * CL_LUSE;               // [CL_KMAX]
 
     {   // tables

@@ -84,7 +84,8 @@ def precompute_all_keypoints(ldm, context, top_indices, args, controllers, num_g
     forward each) -> 512 x 512 maps of the voted tokens (the default `upscale_size` of eval.py:213, hard-wired again in
     the `/ 512.0` of :192-195) -> arg-max or intensity-weighted location.  Here `args.images_per_forward` images' views
     form ONE network batch, and the images are sharded over the ranks (position p of the shuffled order belongs to rank
-    p % world); one all-gather of the [N,K,2] locations, every rank returns all of them in order.
+    p % world); one all-gather of the [N,K,2] locations and one of the annotations (each rank reads ONLY its own images'
+    items, once: pixels and annotations together), every rank returns all of them in order.
     `dataset`: any `{"img"[, "kpts", "visibility"]}` dataset (default: `build_dataset(args)`; `synthetic` / `custom` have no
     annotations => targets None).  `draws = (order [N], noise [N*n,4,h,w], thetas [N*n,2,3])` injects the loader order
     and the per-view draws in the reference's draw order (parity tests; the reference takes them from the global RNGs)."""
@@ -105,15 +106,15 @@ def precompute_all_keypoints(ldm, context, top_indices, args, controllers, num_g
     group = max(1, int(getattr(args, "images_per_forward", 4)))
     idx = torch.as_tensor(top_indices).long()
     found, targets, vis = [], [None] * total, [None] * total
-    for p in range(total):                                          # annotations are host data: every rank reads its own copy
-        item = dataset[order[p]]
-        if "kpts" in item:
-            targets[p] = torch.as_tensor(item["kpts"])
-        if "visibility" in item:
-            vis[p] = torch.as_tensor(item["visibility"])
     for g0 in range(0, len(mine), group):
         pos = mine[g0:g0 + group]
-        imgs = torch.stack([torch.as_tensor(dataset[order[p]]["img"]) for p in pos]).to(dev)
+        items = [dataset[order[p]] for p in pos]                    # ONE load per image: pixels and annotations together
+        imgs = torch.stack([torch.as_tensor(it["img"]) for it in items]).to(dev)
+        for p, it in zip(pos, items):
+            if "kpts" in it:
+                targets[p] = torch.as_tensor(it["kpts"]).cpu()
+            if "visibility" in it:
+                vis[p] = torch.as_tensor(it["visibility"]).cpu()
         rows = [r for p in pos for r in range(p * n_aug, (p + 1) * n_aug)]
         maps = run_images_with_context_augmented(
             ldm, imgs, context, idx, controllers={dev: controller}, layers=args.layers,
@@ -132,6 +133,15 @@ def precompute_all_keypoints(ldm, context, top_indices, args, controllers, num_g
         parts = [torch.empty_like(pad) for _ in range(world)]
         torch.distributed.all_gather(parts, pad)
         source = torch.stack([parts[p % world][p // world] for p in range(total)])
+        # annotations travel with the locations: each rank read only its own images' items
+        ann = [None] * world
+        torch.distributed.all_gather_object(ann, ({p: targets[p] for p in mine if targets[p] is not None},
+                                                  {p: vis[p] for p in mine if vis[p] is not None}))
+        for tg, vs in ann:
+            for p, v in tg.items():
+                targets[p] = v
+            for p, v in vs.items():
+                vis[p] = v
     else:
         source = local
     have_t, have_v = all(t is not None for t in targets), all(v is not None for v in vis)

@@ -92,6 +92,86 @@ def build_dataset(args):
 
 
 # ---------------------------------------------------------------------------------------------
+# host input pipeline: the reference's DataLoader iteration, one group ahead          optimize.py:333-347
+# ---------------------------------------------------------------------------------------------
+def _group_indices(args, n_items, draws, accum, group, rank, world):
+    """Generator of (iteration counter, dataset indices) for successive groups of this rank, in the loop's order:
+    `draws[0]` when the caller injects the order (parity tests), otherwise epoch-wise shuffled, rank-sharded indices from a
+    generator seeded by `args.seed` (every rank draws the same permutation and takes elements rank, rank+world, ...)."""
+    shuffle_gen = torch.Generator(device="cpu").manual_seed(getattr(args, "seed", 0) + 1234)
+    order, cursor = [], 0
+    for step in range(int(args.num_steps)):
+        done = 0
+        while done < accum:
+            n = min(group, accum - done)
+            it = step * accum + done
+            idx = [int(i) for i in draws[0][it:it + n]] if draws is not None else []
+            while len(idx) < n:
+                if cursor >= len(order):
+                    perm = torch.randperm(n_items, generator=shuffle_gen).tolist()
+                    order, cursor = skp_dist.shard_indices(perm, rank, world), 0
+                    if not order:
+                        raise ValueError("dataset smaller than the data-parallel width")
+                idx.append(order[cursor]); cursor += 1
+            yield it, idx
+            done += n
+
+
+class GroupLoader:
+    """Iterator of (iteration counter, indices, images [n,3,H,W]) over `index_iter`.
+
+    With `workers` > 0 and a host-resident dataset the NEXT group is decoded while the GPU works on the current one:
+    `workers` threads call `dataset[i]["img"]` (file decode + resize release the GIL), one assembler thread stacks the
+    items into page-locked memory, and the launch thread only queues one asynchronous H2D copy on its stream (12.6 MB per
+    4 x 512^2 group).  The pinned block goes back to torch's host allocator, which recycles it only after the copy's event
+    has completed, so the launch thread may run any number of steps ahead of the GPU.  A device-resident dataset
+    (tensors already on the GPU) or `workers=0` is the synchronous loop: nothing to hide.  The sequence of indices and the
+    pixel values are identical in both modes."""
+
+    def __init__(self, dataset, index_iter, device, workers=4):
+        self.dataset, self.it, self.device = dataset, iter(index_iter), torch.device(device)
+        self.workers = max(0, int(workers))
+        self.pool = self.assembler = self.pending = None
+        if self.workers and self.device.type == "cuda":
+            probe = dataset[0]["img"]
+            if torch.is_tensor(probe) and probe.device.type == "cpu":
+                from concurrent.futures import ThreadPoolExecutor
+                self.pool = ThreadPoolExecutor(self.workers, thread_name_prefix="skp-decode")
+                self.assembler = ThreadPoolExecutor(1, thread_name_prefix="skp-assemble")
+                self._submit()
+
+    def _load(self, idx):
+        items = list(self.pool.map(lambda i: self.dataset[i]["img"], idx))
+        return torch.stack(items).pin_memory()
+
+    def _submit(self):
+        nxt = next(self.it, None)
+        self.pending = None if nxt is None else (nxt, self.assembler.submit(self._load, nxt[1]))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.assembler is None:
+            it, idx = next(self.it)
+            return it, idx, torch.stack([self.dataset[i]["img"] for i in idx])
+        if self.pending is None:
+            raise StopIteration
+        (it, idx), fut = self.pending
+        batch = fut.result()
+        self._submit()                                           # group g+1 decodes while group g runs on the GPU
+        return it, idx, batch.to(self.device, non_blocking=True)
+
+    def close(self):
+        if self.assembler is not None:
+            if self.pending is not None:
+                self.pending[1].cancel()
+            self.assembler.shutdown(wait=True)
+            self.pool.shutdown(wait=True)
+            self.assembler = self.pool = self.pending = None
+
+
+# ---------------------------------------------------------------------------------------------
 # one accumulation group on this rank
 # ---------------------------------------------------------------------------------------------
 def image_losses(attn_map, attn_map_t, theta_row, args):
@@ -194,13 +274,17 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
 
 
 def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
-                       from_where=["down_cross", "mid_cross", "up_cross"], draws=None, trajectory_out=None):
+                       from_where=["down_cross", "mid_cross", "up_cross"], draws=None, trajectory_out=None,
+                       step_callback=None):
     """Reference signature (optimize.py:269-276).  `num_gpus` = devices driven by THIS process (1); the
     data-parallel width is `num_gpus * world_size`.  Returns the detached embedding [1,T,768].
     `draws = (order, noise, thetas)` injects THIS rank's image order [steps*accum], the noise of every forward in the
     reference's draw order ([2*steps*accum,4,h,w]: image view, warped view, next image ...) and the affine matrices
     [steps*accum,2,3] (parity tests; the reference takes all three from the global RNGs, optimize.py:333-365);
-    `trajectory_out`, a list, receives the embedding after every optimizer step."""
+    `trajectory_out`, a list, receives the embedding after every optimizer step; `step_callback(step)` runs after every
+    optimizer step (tools/protocol_bench.py reads its clocks there).  Images come through `GroupLoader`: the reference's
+    `DataLoader` iteration (optimize.py:333-347) as a one-group-ahead host pipeline (`args.loader_workers`, 0 = the
+    synchronous loop); the image ORDER is the same either way."""
     world, rank = skp_dist.world_size(), skp_dist.rank()
     width = num_gpus * world
     if args.batch_size < width or args.batch_size % width:
@@ -219,49 +303,45 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
     optimizer = torch.optim.Adam([context], lr=args.lr)
     reducer = skp_dist.EmbeddingReducer(context, optimizer)
     group = max(1, min(accum, getattr(args, "images_per_forward", accum)))
-    shuffle_gen = torch.Generator(device="cpu").manual_seed(getattr(args, "seed", 0) + 1234)
-    order, cursor = [], 0
     log_every = getattr(args, "log_interval", 50)
     # opt-in (off: the reference encodes both views every step): latents of the un-warped views kept per dataset index,
     # at most cache_latents_max entries (64 KB each at 512^2)
     latent_cache = {} if getattr(args, "cache_latents", False) else None
     cache_max = int(getattr(args, "cache_latents_max", 200_000))
+    loader = GroupLoader(dataset, _group_indices(args, len(dataset), draws, accum, group, rank, world), dev,
+                         workers=int(getattr(args, "loader_workers", 4)))
     start = it_start = time.time()
-    for step in range(int(args.num_steps)):
-        running = torch.zeros(3, device=dev)
-        done = 0
-        while done < accum:
-            n = min(group, accum - done)
-            idx, inject = [], {}
-            if draws is not None:
-                it = step * accum + done                         # this rank's iteration counter (optimize.py:339)
-                idx = [int(i) for i in draws[0][it:it + n]]
-                pair = torch.as_tensor(draws[1][2 * it:2 * (it + n)]).to(dev)
-                inject = dict(noise=torch.cat([pair[0::2], pair[1::2]]), thetas=torch.as_tensor(draws[2][it:it + n]))
-            while len(idx) < n:                                  # epoch-wise shuffled, rank-sharded indices
-                if cursor >= len(order):
-                    perm = torch.randperm(len(dataset), generator=shuffle_gen).tolist()
-                    order, cursor = skp_dist.shard_indices(perm, rank, world), 0
-                    if not order:
-                        raise ValueError("dataset smaller than the data-parallel width")
-                idx.append(order[cursor]); cursor += 1
-            images = torch.stack([dataset[i]["img"] for i in idx])
-            if latent_cache is not None and len(latent_cache) + n > cache_max:
-                latent_cache.clear()
-            running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size,
-                                              latent_cache=latent_cache, ids=idx, **inject))
-            done += n
-        reducer.step()
-        if trajectory_out is not None:
-            trajectory_out.append(context.detach().clone())
-        if log_every and (step + 1) % log_every == 0:
-            skp_dist.allreduce_sum_(running)                     # every rank holds its share of the batch mean
-        if log_every and (step + 1) % log_every == 0 and rank == 0:
-            r = running.tolist()
-            print(f"step {step + 1}: loss {r[0]:.6f} equivariance {r[1] * args.equivariance_attn_loss_weight:.6f} "
-                  f"sharpening {r[2] * args.sharpening_loss_weight:.6f} "
-                  f"({(time.time() - it_start) / log_every:.3f} s/step on rank 0)", flush=True)
-            it_start = time.time()
+    try:
+        for step in range(int(args.num_steps)):
+            running = torch.zeros(3, device=dev)
+            done = 0
+            while done < accum:
+                it, idx, images = next(loader)
+                n = len(idx)
+                inject = {}
+                if draws is not None:                            # `it` = this rank's iteration counter (optimize.py:339)
+                    pair = torch.as_tensor(draws[1][2 * it:2 * (it + n)]).to(dev)
+                    inject = dict(noise=torch.cat([pair[0::2], pair[1::2]]), thetas=torch.as_tensor(draws[2][it:it + n]))
+                if latent_cache is not None and len(latent_cache) + n > cache_max:
+                    latent_cache.clear()
+                running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size,
+                                                  latent_cache=latent_cache, ids=idx, **inject))
+                done += n
+            reducer.step()
+            if trajectory_out is not None:
+                trajectory_out.append(context.detach().clone())
+            if step_callback is not None:
+                step_callback(step)
+            if log_every and (step + 1) % log_every == 0:
+                skp_dist.allreduce_sum_(running)                 # every rank holds its share of the batch mean
+            if log_every and (step + 1) % log_every == 0 and rank == 0:
+                r = running.tolist()
+                print(f"step {step + 1}: loss {r[0]:.6f} equivariance {r[1] * args.equivariance_attn_loss_weight:.6f} "
+                      f"sharpening {r[2] * args.sharpening_loss_weight:.6f} "
+                      f"({(time.time() - it_start) / log_every:.3f} s/step on rank 0)", flush=True)
+                it_start = time.time()
+    finally:
+        loader.close()
     if rank == 0:
         print(f"optimization took {time.time() - start} seconds")
     return context.detach()
@@ -275,6 +355,6 @@ def default_args(**over):
              equivariance_attn_loss_weight=1000, layers=[0, 1, 2, 3], noise_level=-1, sigma=2.0,
              augment_degrees=15, augment_scale=[0.8, 1.0], augment_translate=[0.25, 0.25], wandb=False,
              model_type="sd-legacy/stable-diffusion-v1-5", seed=0, image_size=512, log_interval=50,
-             cache_latents=False, cache_latents_max=200_000)
+             cache_latents=False, cache_latents_max=200_000, loader_workers=4)
     a.update(over)
     return SimpleNamespace(**a)
