@@ -278,6 +278,22 @@ int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int W);
 int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
                        int B, int Cin, int Cout, int H, int W, void* stream);
 
+/* The Winograd F(4x4,3x3) convolution on the BF16 matrix cores with three-term operand splits (skp_conv_wino4s.hip): fp32 in /
+ * out / accumulate; every fp32 operand of the transform-domain products is the exact sum of three bf16 terms h + m + l, the six
+ * products h.h + h.m + m.h + h.l + l.h + m.m run on v_mfma_f32_16x16x32_bf16 (6 / 16 of the fp32 instructions' matrix time).  bf16
+ * keeps the fp32 exponent range: as accurate as skp_conv3x3_f4_f32 at any input scale (profiles/r05_conv_split.md).  Same role
+ * on the path as skp_conv3x3_f4_f32 (the frozen 3x3 convolutions, ptp_utils.py:227-229, 289-304); OPT-IN (the line of record
+ * stays on the fp32 instructions).  Shapes: Cin % 16 == 0, Cout % 64 == 0, H, W % 4 == 0 (skp_conv3x3_f4s_ok; else SKP_E_RANGE).
+ * Us: 36 * Cin * Cout * 3 bf16 from skp_conv3x3_f4s_filter_f32 (flip_transpose as skp_conv3x3_filter_f32).  workspace:
+ * skp_conv3x3_f4s_workspace() bytes for the K-split partials (NULL forces an unsplit launch).  stats: optional
+ * [B][Cout][skp_conv3x3_f4s_stats_blocks()][2] = {mean, sum (y - mean)^2} per 16-tile block (0 blocks = not available). */
+int skp_conv3x3_f4s_ok(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4s_filter_f32(const void* w, void* Us, int Cout, int Cin, int flip_transpose, void* stream);
+int64_t skp_conv3x3_f4s_workspace(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4s_stats_blocks(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_f4s_f32(const void* x, const void* Us, const void* bias, const void* residual, void* y, void* workspace,
+                        float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
+
 /* Output statistics for the GroupNorm that follows a convolution (diffusers ResnetBlock2D: conv1 -> norm2, conv2 + shortcut
  * -> the next block's norm1 [third party]): the convolution epilogues leave per-(image, channel, pixel-block) sums of their
  * OUTPUT (after bias / shortcut) behind, and the norm takes its mean / variance from them instead of re-reading the

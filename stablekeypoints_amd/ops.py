@@ -838,6 +838,46 @@ def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None, out=None, stats
     return y
 
 
+def _wino4s_filters(weight, backward):
+    """Three bf16 planes of the F(4x4,3x3) transformed filter of a frozen weight (36*Cin*Cout*3 bf16), built once and kept
+    resident (csrc/skp_conv_wino4s.hip: the split form)."""
+    key = "_skp_wino4s_bwd" if backward else "_skp_wino4s_fwd"
+    hit = getattr(weight, key, None)
+    tag = (weight._version, weight.data_ptr())
+    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
+        return hit[1]
+    w = _dev(weight.detach(), "weight")
+    co, ci = w.shape[:2]
+    Us = torch.empty(36 * co * ci * 3, device=w.device, dtype=torch.int16)
+    if backward:
+        N.check(N.lib().skp_conv3x3_f4s_filter_f32(w.data_ptr(), Us.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_f4s_filter_f32")
+    else:
+        N.check(N.lib().skp_conv3x3_f4s_filter_f32(w.data_ptr(), Us.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_f4s_filter_f32")
+    setattr(weight, key, (tag, Us))
+    return Us
+
+
+def _conv3x3_f4s_raw(x, Us, bias, cout, split=True, residual=None, out=None, stats=None):
+    """y = conv3x3(x) on the bf16 matrix cores with three-term operand splits (fp32 in / out / accumulate)."""
+    B, ci, H, W = x.shape
+    y = out if out is not None else torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
+    nbytes = N.lib().skp_conv3x3_f4s_workspace(B, ci, cout, H, W) if (split and stats is None) else 0
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    N.check(N.lib().skp_conv3x3_f4s_f32(x.data_ptr(), Us.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                        ws.data_ptr() if ws is not None else None, stats.data_ptr() if stats is not None else None,
+                                        B, ci, cout, H, W, _stream()), "skp_conv3x3_f4s_f32")
+    return y
+
+
+def conv3x3_f4s(x, weight, bias=None, residual=None, backward=False):
+    """Direct entry to the split form (tests / tools): forward conv3x3 of `weight` [Cout,Cin,3,3], or with `backward` the
+    input-gradient convolution (x = dy [B,Cout,H,W] -> [B,Cin,H,W])."""
+    x = _dev(x, "x")
+    cout = weight.shape[1] if backward else weight.shape[0]
+    return _conv3x3_f4s_raw(x, _wino4s_filters(weight, backward), bias, int(cout), residual=residual)
+
+
 def _wino4r_filters(weight, backward):
     """The 9 taps of a frozen weight in MFMA operand order for the raw-filter form (9*Cin*Cout floats), built once."""
     key = "_skp_wino4r_bwd" if backward else "_skp_wino4r_fwd"
