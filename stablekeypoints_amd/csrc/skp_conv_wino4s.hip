@@ -19,9 +19,9 @@
 // the second slot's (any K order is fine as long as both operands use it).  Two operand tuples per side give all six products
 // in three instructions:      MH = [m01 h01 m23 h23]      HL = [h01 l01 h23 l23]
 //       A.MH . B.HL = m.h + h.l        A.HL . B.MH = h.m + l.h        A.MH . B.MH = m.m + h.h
-// Filter in memory:  Us[cin / 16][cout / 16][p][kq][cout % 16][m01 h01 m23 h23 l01 l23]   (24 bytes per lane and position: MH is one
-//                    16-byte load, HL is built from it and the 8-byte l load by four register moves; the 36 positions of a wave's
-//                    (stage, 16 channels) block are one contiguous 54 KB stream)
+// Filter in memory:  Us[cin / 16][cout / 16][p][ 64 lanes x (m01 h01 m23 h23) | 64 lanes x (l01 l23) ]   (24 bytes per lane and position:
+//                    MH is one fully coalesced 16-byte load, HL is built from it and the 8-byte l load by four register moves; the
+//                    36 positions of a wave's (stage, 16 channels) block are one contiguous 54 KB stream)
 // Input in LDS:      [half][18 positions][MH | HL][kq][32 tiles][16 bytes]   (h is stored twice: both tuples are single aligned
 //                    16-byte reads, and the thread that produced a channel pair writes (m, h) and (h, l) as two 8-byte stores)
 //
@@ -34,6 +34,7 @@
 // kernel is VALU-issue bound at ~5.5k cycles per stage -- still 2x the fp32 form's 11k for the same products.
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 #include "skp_common.h"
 #include "skp_wino4_common.h"
 #include <stdlib.h>
@@ -46,7 +47,7 @@ namespace {
 __device__ __forceinline__ unsigned short w4s_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __device__ __forceinline__ float w4s_bf16_float(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 
-// ---- filter transform + split: Us[c16][cb][p][kq][i16][m01 h01 m23 h23 l01 l23] ----
+// ---- filter transform + split: Us[c16][cb][p][ 64 lanes x (m01 h01 m23 h23) | 64 lanes x (l01 l23) ], lane = 16 kq + cout % 16 ----
 __global__ void skp_wino4s_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ Us, int Cout, int Cin, int flip_t) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Cout * Cin) return;
@@ -88,15 +89,21 @@ __global__ void skp_wino4s_filter_kernel(const float* __restrict__ w, unsigned s
             const unsigned short m = w4s_bf16_bits(r1);
             const unsigned short l = w4s_bf16_bits(r1 - w4s_bf16_float(m));
             const int p = i * 6 + j;
-            unsigned short* dst = Us + ((((size_t)(c16 * CB + cb) * 36 + p) * 4 + kq) * 16 + i16) * 12;
-            dst[(e >> 1) * 4 + (e & 1)] = m; dst[(e >> 1) * 4 + 2 + (e & 1)] = h; dst[8 + e] = l;
+            unsigned short* blk = Us + ((size_t)(c16 * CB + cb) * 36 + p) * 768;          // 1536 bytes: MH tuples of the 64 lanes, then their l pairs
+            const int ln = kq * 16 + i16;
+            blk[ln * 8 + (e >> 1) * 4 + (e & 1)] = m; blk[ln * 8 + (e >> 1) * 4 + 2 + (e & 1)] = h; blk[512 + ln * 4 + e] = l;
         }
 }
 
 constexpr int W4S_POS_B = 2 * 4 * 32 * 16;         // one position: [MH | HL][4 kq][32 tiles][16 bytes] = 4 KB
 constexpr int W4S_HALF_B = 18 * W4S_POS_B;         // one half-stage buffer: 72 KB
 constexpr int W4S_SEG_B = 12 * W4S_POS_B;          // LDS offsets are 16-bit immediates: three base registers, 12 positions (48 KB) apart
-constexpr int W4S_RING = 4;                        // filter ring slots (divides 36): prefetch distance 3 positions (~300 cycles)
+#ifndef W4S_ABL                                    // lab builds only (tools/split_ablate.sh): 1 no side jobs, 2 no filter loads, 4 no MFMAs, 8 no LDS operand reads,
+                                                   // 16 no patch loads, 32 no column pass, 64 no row transform, 128 no split arithmetic, 256 no LDS stores, 512 truncating split
+#define W4S_ABL 0
+#endif
+constexpr int W4S_RING = 9;                        // filter ring slots (divides 36): prefetch distance 8 positions.  VMEM returns in order, so
+                                                   // a filter load queued behind the next stage's patch loads (HBM) inherits their latency
 
 // three bf16 terms of a pair of fp32 values (the two input channels of this thread): packed dwords h, m, l
 __device__ __forceinline__ unsigned w4s_cvt_pk(float lo, float hi) {       // {bf16(lo), bf16(hi)}, round to nearest even
@@ -111,6 +118,35 @@ __device__ __forceinline__ void w4s_split(float a, float b, unsigned& h, unsigne
     const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
     l = w4s_cvt_pk(sa, sb);
 }
+
+// ---- accumulators ---------------------------------------------------------------------------------------------------
+// 36 positions x 2 tile blocks x 4 registers = 288 accumulator registers; a wave owns 256 AGPRs + 256 VGPRs.  Left to the
+// register allocator, the 32 that do not fit the AGPR file get shuttled through temporaries around every MFMA (and one
+// unlucky schedule turned ALL of them into VGPR <-> AGPR copies).  So: positions 0-31 live in a[0:255] by NAME -- their MFMAs
+// are inline assembly, the compiler never sees those registers (every statement lists the whole AGPR file as clobbered, so
+// it keeps nothing of its own there; audit: no compiler-generated v_accvgpr_* may appear in the .s) -- and positions 32-35 are
+// ordinary variables, which the allocator then has to keep in VGPRs (v_mfma takes a VGPR accumulator as well).
+#define W4S_AGPR_CLOBBERS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
+// NOP: the A tuple was assembled by register moves just before the statement: the matrix instruction must not read a VGPR
+// in the two cycles after a VALU wrote it, and nothing pads hazards around / inside an asm statement (measured: NaNs without)
+template <int T, bool NOP>   // accumulator tuple T (0..63): a[4T : 4T + 3] += A . B
+__device__ __forceinline__ void w4s_mfma_named(const f32x4& A, const f32x4& B) {
+    if (NOP) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(A), "v"(B) : W4S_AGPR_CLOBBERS);
+    else asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * T), "n"(4 * T + 3), "v"(A), "v"(B) : W4S_AGPR_CLOBBERS);
+}
+// the same instruction with a VGPR accumulator (positions 32-35): also assembly, so that the compiler never allocates an
+// AGPR temporary for an MFMA of its own -- it would pick one of the named registers
+__device__ __forceinline__ void w4s_mfma_vgpr(f32x4& acc, const f32x4& A, const f32x4& B) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B) : W4S_AGPR_CLOBBERS);
+}
+template <int R>
+__device__ __forceinline__ float w4s_acc_read() {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v) : "n"(R));
+    return v;
+}
+template <class F, int... I>
+__device__ __forceinline__ void w4s_unroll(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 
 template <bool STATS>
 __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
@@ -148,13 +184,18 @@ __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
     const i32x4 xrs = skp_make_rsrc(a.x, a.x_bytes);
     const i32x4 urs = skp_make_rsrc(a.U, a.u_bytes);
     f32x2 d[2][6][3];                                // [channel][row][column pair]: pairs (c0,c5), (c1,c2), (c3,c4)
-    auto load_row = [&](int cin0, int e, int i) {
+    f32x4 ldmid;
+    auto load_part = [&](int cin0, int e, int i, int part) {     // one of the three loads of a patch row
         const int so = (cin0 + e) * HW * 4;
-        const f32x4 mid = skp_buf_load_f32x4(xrs, roff[i], so, 0);
-        d[e][i][0][0] = skp_buf_load_f32(xrs, lok ? roff[i] - 4 : SKP_OOB, so, 0);
-        d[e][i][1] = f32x2{mid[0], mid[1]};
-        d[e][i][2] = f32x2{mid[2], mid[3]};
-        d[e][i][0][1] = skp_buf_load_f32(xrs, rok ? roff[i] + 16 : SKP_OOB, so, 0);
+        if (part == 0) {
+            ldmid = skp_buf_load_f32x4(xrs, roff[i], so, 0);
+            d[e][i][1] = f32x2{ldmid[0], ldmid[1]};
+            d[e][i][2] = f32x2{ldmid[2], ldmid[3]};
+        } else if (part == 1) {
+            d[e][i][0][0] = skp_buf_load_f32(xrs, lok ? roff[i] - 4 : SKP_OOB, so, 0);
+        } else {
+            d[e][i][0][1] = skp_buf_load_f32(xrs, rok ? roff[i] + 16 : SKP_OOB, so, 0);
+        }
     };
     auto col_pass = [&](int e, int k) {
         f32x2 v[6], t[6];
@@ -164,68 +205,107 @@ __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) d[e][i][k] = t[i];
     };
-    // row i of B^T d B for both channels in three pieces: piece 0 runs the row transform and writes columns 0-1, pieces 1 / 2
-    // split and write columns 2-3 / 4-5 (so that ~40 VALU operations sit beside every position's MFMAs instead of 110 beside one)
-    float tr0[6], tr1[6];
+    // row i of B^T d B for the two channels, cut into steps that ride between the MFMAs of three positions:
+    // row_in1d (the row transform of one channel), split_a (first term + residuals of one column), split_b (the other two terms
+    // + the two 8-byte LDS stores: (m, h) into the MH tuple array, (h, l) into the HL one)
+    float tr[2][6];
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     unsigned char* wseg[3];                          // write bases of LDS segments 0-2 (rows 0-1, rows 2-3, rows 4-5)
 #pragma unroll
     for (int g = 0; g < 3; ++g) wseg[g] = smem + g * W4S_SEG_B + ((cp >> 1) * 32 + tl) * 16 + (cp & 1) * 8;
-    auto row_piece = [&](int i, int piece) {
-        if (piece == 0) {
-            float r0[6] = {d[0][i][0][0], d[0][i][1][0], d[0][i][1][1], d[0][i][2][0], d[0][i][2][1], d[0][i][0][1]};
-            float r1[6] = {d[1][i][0][0], d[1][i][1][0], d[1][i][1][1], d[1][i][2][0], d[1][i][2][1], d[1][i][0][1]};
-            w4_in1d(r0, tr0);
-            w4_in1d(r1, tr1);
-        }
-        unsigned char* dst = wseg[i >> 1] + (i & 1) * 6 * W4S_POS_B;
+    auto row_in1d = [&](int e, int i) {
+        if (W4S_ABL & 64) { tr[e][0] = d[e][i][0][0]; tr[e][1] = d[e][i][1][0]; tr[e][2] = d[e][i][1][1]; tr[e][3] = d[e][i][2][0]; tr[e][4] = d[e][i][2][1]; tr[e][5] = d[e][i][0][1]; return; }
+        float r[6] = {d[e][i][0][0], d[e][i][1][0], d[e][i][1][1], d[e][i][2][0], d[e][i][2][1], d[e][i][0][1]};
+        w4_in1d(r, tr[e]);
+    };
+    // work items of one row (both channels), ~12 VALU operations each with 2-4 independent chains (one wave per SIMD: a chain
+    // of dependent operations issues one instruction per ~5 cycles): I0 / I1 = row transform of channel 0 / 1, A(c) = first
+    // bf16 term + residuals of columns 2c, 2c + 1, B(c) = their other two terms + four 8-byte LDS stores
+    unsigned sp_h[2];
+    float sp_ra[2], sp_rb[2];
+    auto split_a2 = [&](int c) {
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = piece * 2 + jj;
-            unsigned h, m, l;
-            w4s_split(tr0[j], tr1[j], h, m, l);
-            *(u32x2*)(dst + j * W4S_POS_B) = u32x2{m, h};
-            *(u32x2*)(dst + j * W4S_POS_B + W4S_POS_B / 2) = u32x2{h, l};
+        for (int q = 0; q < 2; ++q) {
+            const int j = 2 * c + q;
+            if (W4S_ABL & 128) { sp_h[q] = __builtin_bit_cast(unsigned, tr[0][j]); sp_ra[q] = tr[0][j]; sp_rb[q] = tr[1][j]; continue; }
+            if (W4S_ABL & 512) {
+                sp_h[q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, tr[1][j]), __builtin_bit_cast(unsigned, tr[0][j]), 0x07060302u);
+                sp_ra[q] = tr[0][j] - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tr[0][j]) & 0xffff0000u);
+                sp_rb[q] = tr[1][j] - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, tr[1][j]) & 0xffff0000u);
+                continue;
+            }
+            sp_h[q] = w4s_cvt_pk(tr[0][j], tr[1][j]);
+            sp_ra[q] = tr[0][j] - __builtin_bit_cast(float, sp_h[q] << 16);           // exact
+            sp_rb[q] = tr[1][j] - __builtin_bit_cast(float, sp_h[q] & 0xffff0000u);
         }
+    };
+    auto split_b2 = [&](int i, int c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = 2 * c + q;
+            unsigned m, l;
+            if (W4S_ABL & 128) { m = __builtin_bit_cast(unsigned, sp_ra[q]); l = __builtin_bit_cast(unsigned, sp_rb[q]); }
+            else if (W4S_ABL & 512) {
+                m = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sp_rb[q]), __builtin_bit_cast(unsigned, sp_ra[q]), 0x07060302u);
+                const float sa = sp_ra[q] - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sp_ra[q]) & 0xffff0000u);
+                const float sb = sp_rb[q] - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, sp_rb[q]) & 0xffff0000u);
+                l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+            } else {
+                m = w4s_cvt_pk(sp_ra[q], sp_rb[q]);
+                const float sa = sp_ra[q] - __builtin_bit_cast(float, m << 16), sb = sp_rb[q] - __builtin_bit_cast(float, m & 0xffff0000u);
+                l = w4s_cvt_pk(sa, sb);
+            }
+            if (W4S_ABL & 256) { asm volatile("" : : "v"(m), "v"(l), "v"(sp_h[q])); continue; }
+            unsigned char* dst = wseg[i >> 1] + ((i & 1) * 6 + j) * W4S_POS_B;
+            *(u32x2*)dst = u32x2{m, sp_h[q]};
+            *(u32x2*)(dst + W4S_POS_B / 2) = u32x2{sp_h[q], l};
+        }
+    };
+    // step k (0..5) of the third `t` (0..2) of row i: the eight items sit behind every other MFMA of the row's three positions
+    //   t = 0: I0 I1 . A0 . B0      t = 1: . A1 . B1 . A2      t = 2: . B2 . . . .
+    auto row_step = [&](int i, int t, int k) {
+        if (t == 0) {
+            if (k < 2) row_in1d(k, i);
+            else if (k == 3) split_a2(0);
+            else if (k == 5) split_b2(i, 0);
+        } else if (t == 1) {
+            if (k == 1) split_a2(1);
+            else if (k == 3) split_b2(i, 1);
+            else if (k == 5) split_a2(2);
+        } else if (k == 1) split_b2(i, 2);
     };
 
     const unsigned char* vseg[3];                    // read bases of the three LDS segments
 #pragma unroll
     for (int g = 0; g < 3; ++g) vseg[g] = smem + g * W4S_SEG_B + (kq * 32 + i16) * 16;
 
-    f32x4 acc[36][2];
+    // zero the named accumulators; positions 32-35 are variables
+    w4s_unroll([&](auto rc) { asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(decltype(rc)::value) : W4S_AGPR_CLOBBERS); },
+               std::make_integer_sequence<int, 256>{});
+    f32x4 accv[4][2];
 #pragma unroll
-    for (int p = 0; p < 36; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tb = 0; tb < 2; ++tb) accv[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // filter operand of (position p, stage c16): 24 bytes per lane, [m | h] by one 16-byte load, [l] by an 8-byte one
-    const int u_lane = lane * 24;
+    // filter operand of (position p, stage c16): 24 bytes per lane, [m01 h01 m23 h23] by one 16-byte load, [l01 l23] by an 8-byte one
+    const int u_lane = lane * 16;
     const int u_c16 = (a.Cout >> 4) * (36 * 1536);                  // bytes between stages
     const int u_cb = (cg * 4 + wave) * (36 * 1536);
     f32x4 ua_mh[W4S_RING];
     f32x2 ua_l[W4S_RING];
     auto load_u = [&](int slot, int ub, int p) {                    // ub: scalar byte offset of the (stage, channel block) stream
         ua_mh[slot] = skp_buf_load_f32x4(urs, u_lane, ub + p * 1536, 0);
-        ua_l[slot] = skp_buf_load_f32x2(urs, u_lane + 16, ub + p * 1536, 0);
+        ua_l[slot] = skp_buf_load_f32x2(urs, (u_lane >> 1) + 1024, ub + p * 1536, 0);
     };
-
-    // ---- output role (lane = tile within a 16-block, registers = 4 output channels) ----
-    int o_base[2];
-    bool t_ok[2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int tg = tile0 + tb * 16 + i16;
-        t_ok[tb] = tg < a.nTiles;
-        const int tgc = t_ok[tb] ? tg : 0;
-        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
-        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
-        o_base[tb] = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
-    }
 
     // prologue: stage 0 patches -> column pass -> rows 0-2 into half A; first ring slots
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { load_row(cin_begin, 0, i); load_row(cin_begin, 1, i); }
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int part = 0; part < 3; ++part) load_part(cin_begin, e, i, part);
 #pragma unroll
     for (int q = 0; q < W4S_RING - 1; ++q) load_u(q, (cin_begin >> 4) * u_c16 + u_cb, q);
 #pragma unroll
@@ -233,66 +313,76 @@ __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) row_piece(i, pc);
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) row_step(i, t, k);
     __syncthreads();
 
-    // HALF 0: positions 0-17 (half A); side jobs: rows 3-5 of THIS stage -> half B, then (MODE 0) the patch loads of the next stage.
-    // HALF 1: positions 18-35 (half B); side jobs (MODE 0): column pass of the next stage, its rows 0-2 -> half A.
-    // MODE 1 = the last stage of the workgroup.
+    f32x4 bmh[2], bhl[2];                            // B tuples of the two tile blocks (single-buffered: re-read right after their last use)
+    auto read_mh = [&](int p) {
+        if (W4S_ABL & 8) return;
+        const unsigned char* src = vseg[p / 12] + (p % 12) * W4S_POS_B;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) bmh[tb] = *(const f32x4*)(src + tb * 256);
+    };
+    auto read_hl = [&](int p) {
+        if (W4S_ABL & 8) return;
+        const unsigned char* src = vseg[p / 12] + (p % 12) * W4S_POS_B + W4S_POS_B / 2;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) bhl[tb] = *(const f32x4*)(src + tb * 256);
+    };
+
+    // One position = six MFMAs (16 cycles each on the matrix pipe) with one step of the side jobs behind each: with one wave per
+    // SIMD nothing else hides them.  HALF 0: positions 0-17 (half A); side jobs: rows 3-5 of THIS stage -> half B, then (MODE 0)
+    // the patch loads of the next stage.  HALF 1: positions 18-35 (half B); side jobs (MODE 0): column pass of the next stage,
+    // its rows 0-2 -> half A.  MODE 1 = the last stage of the workgroup.
     auto run_half = [&](int s, auto half_c, auto mode_c) {
         constexpr int HALF = decltype(half_c)::value, MODE = decltype(mode_c)::value;
         const int ub = ((cin_begin >> 4) + s) * u_c16 + u_cb;
-        f32x4 bmh[2], bhl[2];                        // B tuples of the two tile blocks (single-buffered: reloaded right after their last use)
-        auto read_mh = [&](int p) {
-            const unsigned char* src = vseg[p / 12] + (p % 12) * W4S_POS_B;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) bmh[tb] = *(const f32x4*)(src + tb * 256);
-        };
-        auto read_hl = [&](int p) {
-            const unsigned char* src = vseg[p / 12] + (p % 12) * W4S_POS_B + W4S_POS_B / 2;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) bhl[tb] = *(const f32x4*)(src + tb * 256);
-        };
+        const int cin_next = cin_begin + (s + 1) * 16;
         read_hl(HALF * 18);
         read_mh(HALF * 18);
-#pragma unroll
-        for (int pl = 0; pl < 18; ++pl) {
-            constexpr int D = W4S_RING - 1;
-            const int p = HALF * 18 + pl;
-            {   // filter operand of position p + D (wrapping into the next stage)
-                const int q = p + D;
-                if (MODE == 0 || q < 36) load_u(q % W4S_RING, q < 36 ? ub : ub + u_c16, q < 36 ? q : q - 36);
+        w4s_unroll([&](auto plc) {
+            constexpr int PL = decltype(plc)::value, P = HALF * 18 + PL, D = W4S_RING - 1;
+            // Patch loads of the next stage go out as early as their registers are free (VMEM returns in order: the filter loads
+            // queued behind them inherit their HBM latency, so they need a whole half-stage of slack before the column pass):
+            // rows 0-2 were consumed in the previous half, row 3 / 4 / 5 are dead once their row transform has run (PL 0 / 3 / 6).
+            auto side = [&](int k) {
+                if (W4S_ABL & 1) return;
+                if (HALF == 0) {
+                    if (PL < 9) row_step(3 + PL / 3, PL % 3, k);
+                    if (MODE == 0 && !(W4S_ABL & 16)) {
+                        constexpr int LR = PL < 5 ? PL : (PL == 7 ? 5 : -1);       // the patch row loaded beside this position
+                        if (LR >= 0) load_part(cin_next, k / 3, LR, k % 3);
+                    }
+                } else if (MODE == 0) {
+                    if (PL >= 6 && PL < 9) { if (W4S_ABL & 32) return; if (k == 0) col_pass(0, PL - 6); else if (k == 3) col_pass(1, PL - 6); }
+                    else if (PL >= 9) row_step((PL - 9) / 3, (PL - 9) % 3, k);
+                }
+            };
+            {   // filter operand of position P + D (wrapping into the next stage)
+                constexpr int Q = P + D;
+                if (!(W4S_ABL & 2) && (MODE == 0 || Q < 36)) load_u(Q % W4S_RING, Q < 36 ? ub : ub + u_c16, Q < 36 ? Q : Q - 36);
             }
-            if (HALF == 0) {
-                if (pl < 9) row_piece(3 + pl / 3, pl % 3);
-                else if (MODE == 0 && pl < 15) { load_row(cin_begin + (s + 1) * 16, 0, pl - 9); load_row(cin_begin + (s + 1) * 16, 1, pl - 9); }
-            } else if (MODE == 0) {
-                if (pl < 3) { col_pass(0, pl); col_pass(1, pl); }
-                else if (pl < 12) row_piece((pl - 3) / 3, (pl - 3) % 3);
-            }
-            const f32x4 umh = ua_mh[p % W4S_RING];
-            const f32x2 ul = ua_l[p % W4S_RING];
-            const bf16x8 a_mh = __builtin_bit_cast(bf16x8, umh);
-            const bf16x8 a_hl = __builtin_bit_cast(bf16x8, (f32x4{umh[1], ul[0], umh[3], ul[1]}));
-            __builtin_amdgcn_sched_barrier(0);
-            // small terms first: m.h + h.l, h.m + l.h, then m.m + h.h; the two tile blocks alternate (no back-to-back dependency).
-            // Each B tuple is re-read for the next position right after its last use here: >= 4 MFMAs + the next position's side
-            // jobs cover the LDS latency, and the tuples need no second register set.
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-                acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mh, __builtin_bit_cast(bf16x8, bhl[tb]), acc[p][tb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pl + 1 < 18) read_hl(p + 1);
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-                acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hl, __builtin_bit_cast(bf16x8, bmh[tb]), acc[p][tb], 0, 0, 0);
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-                acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_mh, __builtin_bit_cast(bf16x8, bmh[tb]), acc[p][tb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (pl + 1 < 18) read_mh(p + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            const f32x4 umh = ua_mh[P % W4S_RING];
+            const f32x2 ul = ua_l[P % W4S_RING];
+            const f32x4 uhl = {umh[1], ul[0], umh[3], ul[1]};
+            // small terms first: m.h + h.l, h.m + l.h, then m.m + h.h; the two tile blocks alternate
+            auto mfma = [&](auto tbc, auto nopc, const f32x4& A, const f32x4& B) {
+                constexpr int TB = decltype(tbc)::value;
+                if (W4S_ABL & 4) return;
+                if constexpr (P < 32) w4s_mfma_named<2 * P + TB, decltype(nopc)::value != 0>(A, B);
+                else w4s_mfma_vgpr(accv[P - 32][TB], A, B);
+            };
+            using T0 = std::integral_constant<int, 0>;
+            using T1 = std::integral_constant<int, 1>;
+            mfma(T0{}, T0{}, umh, bhl[0]); side(0); __builtin_amdgcn_sched_barrier(0);
+            mfma(T1{}, T0{}, umh, bhl[1]); side(1); if (PL + 1 < 18) read_hl(P + 1); __builtin_amdgcn_sched_barrier(0);
+            mfma(T0{}, T1{}, uhl, bmh[0]); side(2); __builtin_amdgcn_sched_barrier(0);
+            mfma(T1{}, T1{}, uhl, bmh[1]); side(3); __builtin_amdgcn_sched_barrier(0);
+            mfma(T0{}, T0{}, umh, bmh[0]); side(4); __builtin_amdgcn_sched_barrier(0);
+            mfma(T1{}, T0{}, umh, bmh[1]); side(5); if (PL + 1 < 18) read_mh(P + 1); __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, 18>{});
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -308,6 +398,18 @@ __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
     if (STATS) __syncthreads();                      // the epilogue parks statistics in the stage buffers
 
     // ---- output transform (in-lane) + store, as skp_wino4_conv_kernel ----
+    // ---- output role (lane = tile within a 16-block, registers = 4 output channels) ----
+    int o_base[2];
+    bool t_ok[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tg = tile0 + tb * 16 + i16;
+        t_ok[tb] = tg < a.nTiles;
+        const int tgc = t_ok[tb] ? tg : 0;
+        const int b = tgc / a.tilesPerImg, rem = tgc - b * a.tilesPerImg;
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        o_base[tb] = ((b * a.Cout) * a.H + 4 * ty) * a.W + 4 * tx;
+    }
     const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
     const i32x4 rrs = skp_make_rsrc(a.res, a.res ? a.y_bytes : 0u);
     const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
@@ -330,24 +432,28 @@ __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
     }
     load_res(0);
     load_res(1);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results are in the register file before the first read
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    w4s_unroll([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
         const int co = n0 + 4 * kq + r;
         const float bv = bvs[r];
         if (r + 2 < 4) load_res(r + 2);
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
+        w4s_unroll([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value;
             const bool ok = t_ok[tb] && co < a.Cout;
             const int vo = (o_base[tb] + co * HW) * 4;
-            float t[6][4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            float t[6][4];                           // T = M A : rows of the 6x6 tile -> 4 columns
+            w4s_unroll([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                w4s_unroll([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, p = i * 6 + j;
+                    if constexpr (p < 32) m[j] = w4s_acc_read<(2 * p + tb) * 4 + r>();
+                    else m[j] = accv[p - 32][tb][r];
+                }, std::make_integer_sequence<int, 6>{});
                 w4_out1d(m, t[i]);
-            }
+            }, std::make_integer_sequence<int, 6>{});
 #pragma unroll
             for (int ox = 0; ox < 4; ++ox) {
                 float m[6], yv[4];
@@ -361,8 +467,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4s_conv_kernel(Wino4Args a) {
             for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
             if (STATS) w4_park_stats(sst, wave * 8 + r * 2 + tb, lane, rr[r][tb], ok);
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        }, std::make_integer_sequence<int, 2>{});
+    }, std::make_integer_sequence<int, 4>{});
     if (STATS) {                                     // 64 channels x 2 tile blocks = 128 (channel, block) pairs
         __syncthreads();
         if (tid < 128) {

@@ -73,11 +73,11 @@ def main():
             t32.append(timeit(f32, iters)); tsp.append(timeit(spl, iters))
         t32.sort(); tsp.sort()
         m32, msp = t32[len(t32) // 2], tsp[len(tsp) // 2]
-        gf = 2 * 9 * ci * co * B * H * H / 4 / 1e9               # Winograd-domain GF (direct / 4)
+        gf = 2 * 9 * ci * co * B * H * H / 4 / 1e6               # Winograd-domain MFLOP (direct / 4): MFLOP / us = TFLOP/s
         S = ops.N.lib().skp_conv3x3_f4s_workspace(B, ci, co, H, H) // (B * co * H * H * 4) or 1
         row = dict(shape=name, B=B, Cin=ci, Cout=co, H=H, input=kind, f32_kernel="f4r" if raw else "f4", f32_us=m32, split_us=msp,
                    speedup=m32 / msp, f32_err=e32, split_err=esp, err_ratio=esp / e32, split_ksplits=int(S),
-                   f32_tf=gf / m32 * 1e-3, split_tf_equiv=gf / msp * 1e-3)
+                   f32_tf=gf / m32, split_tf_equiv=gf / msp)
         rows.append(row)
         print(f"{name:30s} f32({row['f32_kernel']:3s}) {m32:8.1f} us {row['f32_tf']:6.1f} TF/s | split {msp:8.1f} us {row['split_tf_equiv']:6.1f} TF/s-eq "
               f"S={S:2d} | x{row['speedup']:.2f} | err f32 {e32:.2e} split {esp:.2e} ({row['err_ratio']:.2f}x)", flush=True)
