@@ -218,6 +218,43 @@ def conv_roofline(ops, B, image_size, iters, device):
     return t, direct, nbytes, grid_threads, B, folded
 
 
+def split_conv_probe(ops, B, image_size, iters, device):
+    """The round-5 experiment next to the kernel of record: the same 128 -> 128 launch on the bf16 matrix cores with three-term
+    operand splits (csrc/skp_conv_wino4s.hip, six products per fp32 product, fp32 accumulate) -- plain forms of both kernels,
+    interleaved rounds -- and the two kernels' errors against an fp64 convolution on a 128^2 crop of the same data.  The
+    step does NOT run on it (it is no faster: profiles/r05_conv_split.md); the key records that on the bench's own box."""
+    g = torch.Generator(device="cpu").manual_seed(2)
+    ci = co = 128
+    B = min(B, max(1, (2 ** 31 - 1) // (ci * image_size * image_size * 4)))
+    x = torch.randn(B, ci, image_size, image_size, generator=g).to(device)
+    w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
+    U4, Us = ops._wino4_filters(w, False), ops._wino4s_filters(w, False)
+    y = torch.empty(B, co, image_size, image_size, device=device)
+    f32 = lambda: ops._conv3x3_f4_raw(x, U4, None, co, out=y)
+    spl = lambda: ops._conv3x3_f4s_raw(x, Us, None, co, out=y)
+    for _ in range(4):
+        f32(); spl()
+    times = {"f32": [], "split": []}
+    for _ in range(3):
+        for name, fn in (("f32", f32), ("split", spl)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            times[name].append(e0.elapsed_time(e1) / iters * 1e3)
+    xs = x[:1, :, :min(128, image_size), :min(128, image_size)].contiguous()
+    ref = torch.nn.functional.conv2d(xs.double(), w.double(), padding=1)
+    e32 = (ops._conv3x3_f4_raw(xs, U4, None, co, split=False).double() - ref).abs().max().item()
+    esp = (ops._conv3x3_f4s_raw(xs, Us, None, co, split=False).double() - ref).abs().max().item()
+    t32, tsp = sorted(times["f32"])[1], sorted(times["split"])[1]
+    return {"what": f"128 -> 128 channels at {image_size}^2, {B} rows, plain forms: fp32-instruction kernel vs the split-bf16 kernel",
+            "kernel": "skp_wino4s_conv_kernel (v_mfma_f32_16x16x32_bf16, 3 x bf16 terms per operand, 6 products, fp32 accumulate)",
+            "dtype": "f32 via 3 x bf16 operand split, fp32 accumulate", "fp32_kernel_us": t32, "split_kernel_us": tsp,
+            "speedup": t32 / tsp, "max_err_vs_fp64_ratio": esp / e32, "max_err_vs_fp64": {"fp32_kernel": e32, "split_kernel": esp},
+            "on_path_of_record": False, "status": "measured negative (target was >= 1.4x): stage accounting in profiles/r05_conv_split.md"}
+
+
 def conv_step_forms(ops, B, image_size, iters, device):
     """The same kernel in the forms and at the launch shapes the step actually runs (micro-timed like conv_roofline): the
     first-level VAE convolutions carry the GroupNorm + SiLU of their input in the patch load and leave block statistics
@@ -641,6 +678,11 @@ def main():
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(10, a.kernel_iters // 3), dev)
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows, cv_folded = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         cv_forms = conv_step_forms(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
+        try:
+            f32_split = split_conv_probe(ops, B, min(image_size, 512), max(5, a.kernel_iters // 6), dev) if a.model.startswith("sd") else None
+        except Exception as e:                                    # noqa: BLE001 -- an experiment key never takes the line of record down
+            print(f"bench.py: split-conv probe unavailable ({e})", file=sys.stderr)
+            f32_split = None
         def local_step():                                        # rank 0 only: the step without its collective
             nonlocal cursor
             idx = [(cursor + i) % len(data) for i in range(per_rank)]
@@ -746,6 +788,7 @@ def main():
             "attention_roofline_frac": {"map_fwd_hbm": ach / HBM_PEAK_GBS, "map_bwd_hbm": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS,
                                         "self_attn_fwd_mfma": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
                                         "self_attn_bwd_mfma": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF},
+            "f32_split": f32_split,
             "traffic_live_kernels": sorted(live) if live else None,
             "cpu_baseline": cpu_stats, "verify": verify, "collective_check": coll,
             "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
