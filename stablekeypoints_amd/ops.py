@@ -919,9 +919,15 @@ CONV3X3_MODE = os.environ.get("SKP_CONV3X3", "f4")
 
 
 def conv3x3_f4_ok(x_shape, w_shape):
+    """F(4x4,3x3) serves the launch: >= 32 tiles (one tile block of the transformed-filter kernels), or fewer on the
+    raw-filter form where it is routed (>= 1280 channels on both sides: the 8^2 layers of a 1- or 2-row step -- config 3's
+    per-rank shape -- ran on the library at 120 us per call incl. its layout transposes; the raw-filter kernel takes the
+    same 55 us as at 8 rows, its idle tile lanes cost nothing extra)."""
     b, _, h, w = (int(v) for v in x_shape)
-    return (CONV3X3_MODE == "f4" and h % 4 == 0 and w % 4 == 0 and int(w_shape[0]) % 16 == 0 and int(w_shape[1]) % 16 == 0
-            and b * (h // 4) * (w // 4) >= 32 and 36 * int(w_shape[0]) * int(w_shape[1]) * 4 < 2 ** 31)
+    if not (CONV3X3_MODE == "f4" and h % 4 == 0 and w % 4 == 0 and int(w_shape[0]) % 16 == 0 and int(w_shape[1]) % 16 == 0
+            and 36 * int(w_shape[0]) * int(w_shape[1]) * 4 < 2 ** 31):
+        return False
+    return b * (h // 4) * (w // 4) >= 32 or conv3x3_f4r_ok(x_shape, int(w_shape[0]))
 
 
 def conv3x3_wanted(x_shape, w_shape):
