@@ -365,6 +365,10 @@ def cpu_baseline(ldm_cpu, args):
     `value` is the bench-shape rate (same image size as the GPU line); the C1 rate rides along."""
     from oracle import cpu_path
     ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))                    # the cores this process may actually run on (cgroup / taskset)
+    except AttributeError:
+        usable = ncpu
     g = torch.Generator().manual_seed(0)
     ctx = torch.randn(1, args.tokens, ldm_cpu.unet.config["cross_attention_dim"], generator=g)
     kw = dict(R_up=args.res, furthest_point_num_samples=args.candidates, top_k=args.top_k)
@@ -400,7 +404,10 @@ def cpu_baseline(ldm_cpu, args):
     return {"value": rate, "unit": "images/sec", "cores": best, "kind": "port",
             "sample": f"{size}x{size}: 1 warm-up + 3 timed optimizer steps (batch 1: 2 VAE+UNet forwards with materialised "
                       f"attention, backward, Adam per step), T={args.tokens}, R={args.res}, {sec:.1f} s; torch "
-                      f"{torch.__version__} CPU fp32, {best} threads of {ncpu}",
+                      f"{torch.__version__} CPU fp32, {best} threads of {ncpu} logical CPUs ({usable} in this process's affinity mask); "
+                      "the thread count is the winner of the sweep below, not the host's size: past it the op-level parallel "
+                      "regions of the reference-order path oversubscribe and slow down",
+            "host_cpus": {"os_cpu_count": ncpu, "sched_getaffinity": usable},
             "c1_256": {"value": c1_rate, "steps": c1_steps, "seconds": c1_sec, "sampled": c1_steps < 50,
                        "full_protocol_steps": 50,
                        "what": "BASELINE config 1 shape (256^2, 1 image, batch 1), reference op order"

@@ -596,6 +596,22 @@ constexpr int W4C_RING = 6;                      // ring slots per channel block
 // an XCD stay on one band).  While the LAST stage of a unit runs, its side jobs load and transform the first patches of the
 // NEXT unit (the transform role is retargeted before that stage), so per unit only the epilogue and the filter ring refill
 // are left outside the MFMA loop -- with 8 stages per unit (128 input channels) the prologue + dispatch gap was ~25 % of it.
+// fp32 MFMAs on NAMED accumulators (skp_wino4_common.h): accumulator tuple T = 2 * position + channel block for positions 0-31
+// lives in a[4T : 4T + 3]; positions 32-35 are VGPR tuples.  Operands come straight from buffer loads / LDS reads (no VALU write
+// in front of the statement: no wait states needed).
+template <int P, int CB>
+__device__ __forceinline__ void w4c_mfma(f32x4 (&accv)[4][2], float a, float b) {
+    if constexpr (P < 32)
+        asm volatile("v_mfma_f32_16x16x4_f32 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * (2 * P + CB)), "n"(4 * (2 * P + CB) + 3), "v"(a), "v"(b) : W4_AGPR_CLOBBERS);
+    else
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[P - 32][CB]) : "v"(a), "v"(b) : W4_AGPR_CLOBBERS);
+}
+template <int P, int CB, int R>
+__device__ __forceinline__ float w4c_acc(const f32x4 (&accv)[4][2]) {
+    if constexpr (P < 32) return w4_acc_read<4 * (2 * P + CB) + R>();
+    else return accv[P - 32][CB][R];
+}
+
 template <bool STATS, bool GNF = false>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][16] stage buffers, then [32][64] float2 statistics slots
@@ -733,11 +749,14 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         while (wnext < a.vtotal && !w4_work(a, wnext, tb_n, cg_n, z_n)) wnext += gridDim.x;
         const bool has_next = wnext < a.vtotal;
 
-        f32x4 acc[36][2];                            // [position][channel block]
+        // accumulators [position][channel block]: positions 0-31 by NAME in a[0:255] (w4c_mfma), 32-35 in VGPR tuples
+        w4_unroll([&](auto rc) { asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(decltype(rc)::value) : W4_AGPR_CLOBBERS); },
+                  std::make_integer_sequence<int, 256>{});
+        f32x4 accv[4][2];
 #pragma unroll
-        for (int p = 0; p < 36; ++p)
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) acc[p][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < 2; ++cb) accv[p][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
 
         // MODE 0: a stage of the unit, loading / transforming the unit's next stage on the side; MODE 1: the unit's last stage,
@@ -750,11 +769,11 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
             f32x4 va[3];
             va[0] = vb[0];
             va[1] = vb[64];
-#pragma unroll
-            for (int p = 0; p < 36; ++p) {
+            w4_unroll([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
                 {
                     constexpr int D = W4C_RING - 1;
-                    const int q = p + D;
+                    constexpr int q = p + D;
                     if (MODE == 0 || q < 36) {
                         const int uo = q < 36 ? ub + q * u_p : ub + u_c16 + (q - 36) * u_p;
 #pragma unroll
@@ -768,13 +787,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
                 else if (p >= 27 && p < 30) col_pass(p - 27);
                 else if (p >= 30) row_pass_store((bpar + s + 1) & 1, p - 30);
                 if (p + 2 < 36) va[(p + 2) % 3] = vb[(p + 2) * 64];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        acc[p][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4C_RING][cb][m], va[p % 3][m], acc[p][cb], 0, 0, 0);
+                w4_unroll([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    w4c_mfma<p, 0>(accv, ua[p % W4C_RING][0][m], va[p % 3][m]);
+                    w4c_mfma<p, 1>(accv, ua[p % W4C_RING][1][m], va[p % 3][m]);
+                }, std::make_integer_sequence<int, 4>{});
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            }, std::make_integer_sequence<int, 36>{});
         };
         for (int s = 0; s + 1 < nsteps; ++s) {
             run_stage(s, std::integral_constant<int, 0>{});
@@ -813,23 +832,23 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         constexpr int RD = GNF ? 2 : 3;              // residual rows in flight (the GNF forms carry more state across the epilogue)
 #pragma unroll
         for (int e = 0; e < RD; ++e) load_res(e);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are in the register file before the first read
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int cb = e >> 2, r = e & 3;
+        w4_unroll([&](auto ec) {
+            constexpr int e = decltype(ec)::value, cb = e >> 2, r = e & 3;
             const int co = n0 + cb * 16 + 4 * kq + r;
             const bool ok = t_ok && co < a.Cout;
             const int vo = (o_base + co * HW) * 4;
             const float bv = bvs[e];
             if (e + RD < 8) load_res(e + RD);
             float t[6][4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            w4_unroll([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][cb][r];
+                w4_unroll([&](auto jc) { constexpr int j = decltype(jc)::value; m[j] = w4c_acc<i * 6 + j, cb, r>(accv); },
+                          std::make_integer_sequence<int, 6>{});
                 w4_out1d(m, t[i]);
-            }
+            }, std::make_integer_sequence<int, 6>{});
 #pragma unroll
             for (int ox = 0; ox < 4; ++ox) {
                 float m[6], yv[4];
@@ -843,7 +862,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
             for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[e][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
             if (STATS) w4_park_stats(sst, wave * 8 + e, lane, rr[e], ok);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        }, std::make_integer_sequence<int, 8>{});
         if (STATS) {                                 // 128 channels of one tile block
             __syncthreads();
             if (tid < 128) {
