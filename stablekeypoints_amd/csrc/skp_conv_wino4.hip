@@ -71,6 +71,22 @@ __global__ void skp_wino4_filter_kernel(const float* __restrict__ w, float* __re
         }
 }
 
+// fp32 MFMAs on NAMED accumulators (skp_wino4_common.h): accumulator tuple T = 2 * position + channel block for positions 0-31
+// lives in a[4T : 4T + 3]; positions 32-35 are VGPR tuples.  Operands come straight from buffer loads / LDS reads (no VALU write
+// in front of the statement: no wait states needed).
+template <int P, int CB>
+__device__ __forceinline__ void w4c_mfma(f32x4 (&accv)[4][2], float a, float b) {
+    if constexpr (P < 32)
+        asm volatile("v_mfma_f32_16x16x4_f32 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * (2 * P + CB)), "n"(4 * (2 * P + CB) + 3), "v"(a), "v"(b) : W4_AGPR_CLOBBERS);
+    else
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[P - 32][CB]) : "v"(a), "v"(b) : W4_AGPR_CLOBBERS);
+}
+template <int P, int CB, int R>
+__device__ __forceinline__ float w4c_acc(const f32x4 (&accv)[4][2]) {
+    if constexpr (P < 32) return w4_acc_read<4 * (2 * P + CB) + R>();
+    else return accv[P - 32][CB][R];
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]
@@ -135,11 +151,14 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
         for (int j = 0; j < 6; ++j) *(f32x2*)(dst + j * (4 * 32 * 4)) = f32x2{t0[j], t1[j]};
     };
 
-    f32x4 acc[36][2];
+    // accumulators [position][tile block]: positions 0-31 by NAME in a[0:255] (w4c_mfma), 32-35 in VGPR tuples
+    w4_unroll([&](auto rc) { asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(decltype(rc)::value) : W4_AGPR_CLOBBERS); },
+              std::make_integer_sequence<int, 256>{});
+    f32x4 accv[4][2];
 #pragma unroll
-    for (int p = 0; p < 36; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tb = 0; tb < 2; ++tb) accv[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int C16 = a.Cin >> 4;
     const int co_l = min(n0 + i16, a.Cout - 1);
@@ -181,11 +200,11 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
         va[0][1] = vb[16];
         va[1][0] = vb[128];
         va[1][1] = vb[128 + 16];
-#pragma unroll
-        for (int p = 0; p < 36; ++p) {
+        w4_unroll([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
             {   // filter operand for position p + RING-1 (wrapping into the next stage)
                 constexpr int D = W4_RING - 1;
-                const int q = p + D;
+                constexpr int q = p + D;
                 if (MODE == 0 || q < 36) {
                     const int uo = q < 36 ? ub + q * u_p : ub + u_c16 + (q - 36) * u_p;
                     ua[q % W4_RING] = skp_buf_load_f32x4(urs, uvo, uo, 0);
@@ -205,13 +224,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
                 va[(p + 2) % 3][0] = vb[(p + 2) * 128];
                 va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[p % W4_RING][m], va[p % 3][tb][m], acc[p][tb], 0, 0, 0);
+            w4_unroll([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                w4c_mfma<p, 0>(accv, ua[p % W4_RING][m], va[p % 3][0][m]);
+                w4c_mfma<p, 1>(accv, ua[p % W4_RING][m], va[p % 3][1][m]);
+            }, std::make_integer_sequence<int, 4>{});
             __builtin_amdgcn_sched_barrier(0);
-        }
+        }, std::make_integer_sequence<int, 36>{});
     };
     for (int s = 0; s + 1 < nsteps; ++s) {
         run_stage(s, std::integral_constant<int, 0>{});
@@ -244,24 +263,25 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
     }
     load_res(0);
     load_res(1);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results are in the register file before the first read
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    w4_unroll([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
         const int co = n0 + 4 * kq + r;
         const float bv = bvs[r];
         if (r + 2 < 4) load_res(r + 2);
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
+        w4_unroll([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value;
             const bool ok = t_ok[tb] && co < a.Cout;
             const int vo = (o_base[tb] + co * HW) * 4;
             float t[6][4];                           // T = M A : rows of the 6x6 tile -> 4 columns
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            w4_unroll([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                w4_unroll([&](auto jc) { constexpr int j = decltype(jc)::value; m[j] = w4c_acc<i * 6 + j, tb, r>(accv); },
+                          std::make_integer_sequence<int, 6>{});
                 w4_out1d(m, t[i]);
-            }
+            }, std::make_integer_sequence<int, 6>{});
 #pragma unroll
             for (int ox = 0; ox < 4; ++ox) {
                 float m[6], yv[4];
@@ -275,8 +295,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_kernel(Wino4Args a) {
             for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
             if (STATS) w4_park_stats((f32x2*)vst, wave * 8 + r * 2 + tb, lane, rr[r][tb], ok);
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        }, std::make_integer_sequence<int, 2>{});
+    }, std::make_integer_sequence<int, 4>{});
     if (STATS) {                                     // 64 channels x 2 tile blocks = 128 (channel, block) pairs
         __syncthreads();
         if (tid < 128) {
@@ -424,11 +444,16 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
         for (int k = 0; k < 6; ++k) u_piece(gg, i, k, u);
     };
 
-    f32x4 acc[36][2];
+    // accumulators [position][tile block]: positions 0-31 by NAME in a[0:255] (w4c_mfma), 32-35 in VGPR tuples.  The A operand
+    // here is computed by VALU operations (u_piece) -- of the NEXT row, at least one position before its first MFMA, far
+    // outside the two wait states a VALU write needs in front of an MFMA read.
+    w4_unroll([&](auto rc) { asm volatile("v_accvgpr_write_b32 a[%0], 0" : : "n"(decltype(rc)::value) : W4_AGPR_CLOBBERS); },
+              std::make_integer_sequence<int, 256>{});
+    f32x4 accv[4][2];
 #pragma unroll
-    for (int p = 0; p < 36; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tb = 0; tb < 2; ++tb) accv[p][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- output role (lane = tile within a 16-block, registers = 4 output channels) ----
     int o_base[2];
@@ -463,9 +488,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
         va[0][1] = vb[16];
         va[1][0] = vb[128];
         va[1][1] = vb[128 + 16];
-#pragma unroll
-        for (int p = 0; p < 36; ++p) {
-            const int i = p / 6, j = p - 6 * i;
+        w4_unroll([&](auto pc) {
+            constexpr int p = decltype(pc)::value, i = p / 6, j = p - 6 * i;
             if (p == 0) load_g(gn, c16n);                // the taps first: they come from HBM, the tiles (L2 / MALL) queue behind them
             else if (p <= 18) load_v(c16n, (s + 1) & 1, p - 1);
             if (i < 5) u_piece(g, i + 1, j, ur[(i + 1) & 1]);
@@ -473,13 +497,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
                 va[(p + 2) % 3][0] = vb[(p + 2) * 128];
                 va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[i & 1][j][m], va[p % 3][tb][m], acc[p][tb], 0, 0, 0);
+            w4_unroll([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                w4c_mfma<p, 0>(accv, ur[i & 1][j][m], va[p % 3][0][m]);
+                w4c_mfma<p, 1>(accv, ur[i & 1][j][m], va[p % 3][1][m]);
+            }, std::make_integer_sequence<int, 4>{});
             __builtin_amdgcn_sched_barrier(0);
-        }
+        }, std::make_integer_sequence<int, 36>{});
 #pragma unroll
         for (int t = 0; t < 9; ++t) g[t] = gn[t];
         u_row(g, 0, ur[0]);
@@ -489,24 +513,25 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     }
 
     // ---- output transform (in-lane) + store, as skp_wino4_conv_kernel ----
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results are in the register file before the first read
     __builtin_amdgcn_sched_barrier(0);
     const i32x4 yrs = skp_make_rsrc(a.y + zsplit * a.y_split_stride, a.y_bytes);
     if (PART) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        w4_unroll([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
             const int co = n0 + 4 * kq + r;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
+            w4_unroll([&](auto tbc) {
+                constexpr int tb = decltype(tbc)::value;
                 const bool ok = t_ok[tb] && co < a.Cout;
                 const int vo = (o_base[tb] + co * HW) * 4;
                 float t[6][4];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                w4_unroll([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
                     float m[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                    w4_unroll([&](auto jc) { constexpr int j = decltype(jc)::value; m[j] = w4c_acc<i * 6 + j, tb, r>(accv); },
+                              std::make_integer_sequence<int, 6>{});
                     w4_out1d(m, t[i]);
-                }
+                }, std::make_integer_sequence<int, 6>{});
                 f32x4 o[4];
 #pragma unroll
                 for (int ox = 0; ox < 4; ++ox) {
@@ -520,8 +545,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
 #pragma unroll
                 for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(o[oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+            }, std::make_integer_sequence<int, 2>{});
+        }, std::make_integer_sequence<int, 4>{});
         W4R_STAMP(40);
 #ifdef W4R_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -550,23 +575,23 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     }
     load_res(0);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    w4_unroll([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
         const int co = n0 + 4 * kq + r;
         const float bv = bvs[r];
         if (r + 1 < 4) load_res(r + 1);
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
+        w4_unroll([&](auto tbc) {
+            constexpr int tb = decltype(tbc)::value;
             const bool ok = t_ok[tb] && co < a.Cout;
             const int vo = (o_base[tb] + co * HW) * 4;
             float t[6][4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            w4_unroll([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = acc[i * 6 + j][tb][r];
+                w4_unroll([&](auto jc) { constexpr int j = decltype(jc)::value; m[j] = w4c_acc<i * 6 + j, tb, r>(accv); },
+                          std::make_integer_sequence<int, 6>{});
                 w4_out1d(m, t[i]);
-            }
+            }, std::make_integer_sequence<int, 6>{});
 #pragma unroll
             for (int ox = 0; ox < 4; ++ox) {
                 float m[6], yv[4];
@@ -579,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
 #pragma unroll
             for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        }, std::make_integer_sequence<int, 2>{});
+    }, std::make_integer_sequence<int, 4>{});
 }
 
 // ---- 128-channel form (Cout % 128 == 0): a wave owns 32 output channels x 16 tiles x 36 positions (same 288
@@ -596,22 +621,6 @@ constexpr int W4C_RING = 6;                      // ring slots per channel block
 // an XCD stay on one band).  While the LAST stage of a unit runs, its side jobs load and transform the first patches of the
 // NEXT unit (the transform role is retargeted before that stage), so per unit only the epilogue and the filter ring refill
 // are left outside the MFMA loop -- with 8 stages per unit (128 input channels) the prologue + dispatch gap was ~25 % of it.
-// fp32 MFMAs on NAMED accumulators (skp_wino4_common.h): accumulator tuple T = 2 * position + channel block for positions 0-31
-// lives in a[4T : 4T + 3]; positions 32-35 are VGPR tuples.  Operands come straight from buffer loads / LDS reads (no VALU write
-// in front of the statement: no wait states needed).
-template <int P, int CB>
-__device__ __forceinline__ void w4c_mfma(f32x4 (&accv)[4][2], float a, float b) {
-    if constexpr (P < 32)
-        asm volatile("v_mfma_f32_16x16x4_f32 a[%0:%1], %2, %3, a[%0:%1]" : : "n"(4 * (2 * P + CB)), "n"(4 * (2 * P + CB) + 3), "v"(a), "v"(b) : W4_AGPR_CLOBBERS);
-    else
-        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[P - 32][CB]) : "v"(a), "v"(b) : W4_AGPR_CLOBBERS);
-}
-template <int P, int CB, int R>
-__device__ __forceinline__ float w4c_acc(const f32x4 (&accv)[4][2]) {
-    if constexpr (P < 32) return w4_acc_read<4 * (2 * P + CB) + R>();
-    else return accv[P - 32][CB][R];
-}
-
 template <bool STATS, bool GNF = false>
 __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][16] stage buffers, then [32][64] float2 statistics slots
