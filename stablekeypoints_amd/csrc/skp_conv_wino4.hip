@@ -1036,13 +1036,16 @@ extern "C" int skp_conv3x3_f4_stats_blocks(int B, int Cin, int Cout, int H, int 
 static int wino4_run(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace, float* stats,
                      int B, int Cin, int Cout, int H, int W, void* stream, const float* gncoef = nullptr);
 
-// 1 when skp_conv3x3_f4_gn_f32 serves this launch: 128-channel workgroup form, ONE channel group (the normalisation is
-// applied once per input value), unsplit.  More output-channel groups would redo the SiLU per group: there the separate
-// GroupNorm apply pass is cheaper (profiles/r03_conv_gn_fold.md).
+// 1 when skp_conv3x3_f4_gn_f32 serves this launch: 128-channel workgroup form, unsplit, at most four channel groups.  Every
+// channel group redoes the SiLU of its input patches; since the accumulators are named (no spills in the folded kernel) that
+// costs less than the separate GroupNorm apply pass (one read + one write of the activation) up to the VAE's 512-channel levels:
+// 256 -> 256 @256^2 1 794 -> 1 657 us, 512 -> 512 @128^2 1 580 -> 1 493, 512 -> 512 @64^2 436 -> 401 (tools/gn_fold_bench.py;
+// rounds 3-4 gated at ONE group: profiles/r03_conv_gn_fold.md).  SKP_GN_FOLD_MAX_COUT=<n>: A/B runs.
 extern "C" int skp_conv3x3_f4_gn_ok(int B, int Cin, int Cout, int H, int W) {
     if (wino4_plan(B, Cin, Cout, H, W) != 1) return 0;
     const int tiles = B * (H / 4) * (W / 4);
-    return (wino4_use_c128(Cout, tiles) && Cout <= 128) ? 1 : 0;
+    static const int max_cout = [] { const char* e = getenv("SKP_GN_FOLD_MAX_COUT"); return e ? atoi(e) : 512; }();
+    return (wino4_use_c128(Cout, tiles) && Cout <= max_cout) ? 1 : 0;
 }
 
 // y = conv3x3(silu(x * scale[b,c] + shift[b,c])) (+ bias) (+ residual): the GroupNorm(+offset)+SiLU in front of the

@@ -390,16 +390,18 @@ def test_fused_unwarp_accumulate_vs_torch_ops(n, K, Rm, S):
     torch.testing.assert_close(out[:, covered], ref[:, covered], rtol=5e-4, atol=1e-5)     # north_star bar: 1e-3
 
 
-@pytest.mark.parametrize("B,C,H,W,use_off,use_res", [(2, 128, 256, 256, True, True), (4, 128, 128, 128, False, True),
-                                                     (1, 64, 128, 128, True, False), (2, 64, 96, 128, False, False)])
-def test_group_norm_folded_into_winograd_conv_vs_fp64(B, C, H, W, use_off, use_res, monkeypatch):
+@pytest.mark.parametrize("B,C,H,W,use_off,use_res,cout", [(2, 128, 256, 256, True, True, 128), (4, 128, 128, 128, False, True, 128),
+                                                          (1, 64, 128, 128, True, False, 128), (2, 64, 96, 128, False, False, 128),
+                                                          # round 5: more than one channel group (the VAE's 256- / 512-channel levels)
+                                                          (2, 256, 128, 128, True, True, 256), (4, 128, 256, 256, False, False, 256),
+                                                          (8, 512, 64, 64, True, True, 512)])
+def test_group_norm_folded_into_winograd_conv_vs_fp64(B, C, H, W, use_off, use_res, cout, monkeypatch):
     """conv3x3(silu(GroupNorm(x + off))) + bias + residual with the norm applied inside the convolution's patch load
     (skp_conv3x3_f4_gn_f32) against fp64 torch ops and against the unfolded route (GroupNorm kernel, then convolution);
     statistics once from a pass over x, once from a producing convolution's block sums."""
     import torch.nn.functional as F
     from stablekeypoints_amd import ops
     g = torch.Generator().manual_seed(13)
-    cout = 128
     x = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3).cuda()
     norm = torch.nn.GroupNorm(32, C).cuda()
     with torch.no_grad():
