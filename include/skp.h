@@ -146,8 +146,9 @@ int skp_unwarp_accumulate_f32(const float* M, const float* theta_inv, int n, int
  * autograd): skp_group_norm_coef_f32 leaves (scale, shift) per (sample, channel) -- statistics from the producing
  * convolution's block sums (bs != NULL) or from one pass over x -- and skp_conv3x3_f4_gn_f32 computes
  * conv3x3(silu(x * scale + shift)) with the normalisation applied in its patch load: the GroupNorm apply pass (one read
- * and one write of the activation) disappears.  skp_conv3x3_f4_gn_ok: 1 where the convolution runs with a single
- * output-channel group (Cout <= 128, 128-channel workgroup form, unsplit). */
+ * and one write of the activation) disappears.  skp_conv3x3_f4_gn_ok: 1 where the folded form serves the launch: 128-channel
+ * workgroup form, unsplit, at most four output-channel groups (Cout <= 512; every group redoes the SiLU of its patches, which
+ * is cheaper than the apply pass up to there). */
 int skp_group_norm_coef_f32(const float* x, const float* off, const float* gamma, const float* beta, float* mean, float* rstd,
                             float* coef, const float* bs, int nblk, int pix, float* workspace, int N, int C, int G, int HW,
                             float eps, void* stream);

@@ -189,7 +189,8 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert lib.skp_add_layer_norm_fwd_f32(null, p, p, p, null, p, p, 4, 30, 1e-5, null) == -2        # row width without a plan
     assert lib.skp_add_layer_norm_bwd_f32(p, null, p, p, p, null, 4, 320, null) == -1
     assert lib.skp_unwarp_accumulate_f32(null, p, 1, 1, 32, 64, p, p, 1, null) < 0
-    assert lib.skp_conv3x3_f4_gn_ok(8, 128, 128, 512, 512) == 1 and lib.skp_conv3x3_f4_gn_ok(8, 320, 320, 64, 64) == 0   # one channel group only
+    assert lib.skp_conv3x3_f4_gn_ok(8, 128, 128, 512, 512) == 1 and lib.skp_conv3x3_f4_gn_ok(8, 512, 512, 64, 64) == 1
+    assert lib.skp_conv3x3_f4_gn_ok(8, 640, 640, 32, 32) == 0 and lib.skp_conv3x3_f4_gn_ok(8, 1280, 640, 16, 16) == 0   # <= 4 channel groups, unsplit launches
     assert lib.skp_conv3x3_f4_gn_f32(p, p, null, null, p, null, null, 8, 128, 128, 512, 512, null) == -1              # no coefficients
 
 
