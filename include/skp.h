@@ -212,6 +212,16 @@ int skp_flash_attn_bwd_f32(const float* q, const float* k, const float* v, const
                            const float* lse, float* dq, float* dk, float* dv, float* workspace,
                            int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream);
 
+/* The flash-attention FORWARD on the BF16 matrix cores with three-term operand splits (skp_flash_attn_s.hip; same role and
+ * contract as skp_flash_attn_fwd_f32: out, natural-log lse for the fp32 backward kernels): fp32 in / out, fp32 softmax and
+ * accumulation, every operand of S^T = K.Q^T and O^T += V^T.P^T the exact sum of three bf16 terms, six products per fp32 product
+ * on v_mfma_f32_16x16x32_bf16.  K / V are split once per call into tile images in `workspace`
+ * (skp_flash_attn_fwd_split_workspace() bytes, REQUIRED).  OPT-IN experiment; d in {40, 80} (skp_flash_attn_fwd_split_ok). */
+int skp_flash_attn_fwd_split_ok(int B, int Bk, int H, int N, int Nk, int d);
+int64_t skp_flash_attn_fwd_split_workspace(int B, int Bk, int H, int N, int Nk, int d);
+int skp_flash_attn_fwd_split_f32(const float* q, const float* k, const float* v, float* out, float* lse, void* workspace,
+                                 int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream);
+
 /* Flash-style self-attention (ptp_utils.py:493-506 with context = x) for the long image-token sequences: fp32 MFMA,
  * 64-key tiles in LDS, online softmax; the [B*h,N,N] scores are never materialised.
  * q, k, v, out: [B,N,H*d]; lse: [B,H,N] (natural log).  Limits: d in {8,16,32,40,64,80,160}. */

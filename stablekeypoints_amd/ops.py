@@ -631,6 +631,35 @@ def self_attn_supported(C: int, heads: int) -> bool:
     return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS
 
 
+# EXPERIMENT (opt-in, never the path of record): the flash-attention FORWARD on the bf16 matrix cores with three-term operand
+# splits (csrc/skp_flash_attn_s.hip; same out / lse contract, the fp32 backward kernels run on its lse).  SKP_FLASH_SPLIT=1
+# routes the layers it serves (d = 40 / 80, >= 1024 keys) through it; bench.py reports that step as `f32_split`.
+FLASH_SPLIT = os.environ.get("SKP_FLASH_SPLIT", "0") == "1"
+FLASH_SPLIT_MIN_KEYS = 1024
+
+
+def flash_split_ok(B, Bk, heads, Nq, Nk, d) -> bool:
+    return Nk >= FLASH_SPLIT_MIN_KEYS and bool(N.lib().skp_flash_attn_fwd_split_ok(B, Bk, heads, Nq, Nk, d))
+
+
+def _flash_fwd_split(q, k, v, out, lse, heads, scale):
+    B, Nq, C = q.shape
+    Bk, Nk, _ = k.shape
+    nbytes = N.lib().skp_flash_attn_fwd_split_workspace(B, Bk, heads, Nq, Nk, C // heads)
+    ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+    N.check(N.lib().skp_flash_attn_fwd_split_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), ws.data_ptr(),
+                                                 B, Bk, heads, Nq, Nk, C // heads, scale, _stream()), "skp_flash_attn_fwd_split_f32")
+
+
+def flash_attn_fwd_split(q, k, v, heads: int, scale: float):
+    """Direct entry (tests / tools): (out, lse) of the split forward."""
+    q, k, v = _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
+    out = torch.empty_like(q)
+    lse = torch.empty(q.shape[0], heads, q.shape[1], device=q.device, dtype=torch.float32)
+    _flash_fwd_split(q, k, v, out, lse, heads, float(scale))
+    return out, lse
+
+
 class FlashAttnFn(torch.autograd.Function):
     """out = merge_heads(softmax(scale q k^T) v); q [B,N,C], k, v [Bk,Nk,C] with Bk in {1,B}; key-tiled online
     softmax, scores never materialised.  Self-attention is the Bk == B, Nk == N case."""
@@ -642,9 +671,12 @@ class FlashAttnFn(torch.autograd.Function):
         Bk, Nk, _ = k.shape
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
-        N.check(N.lib().skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                                               B, Bk, heads, Nq, Nk, C // heads, float(scale), _stream()),
-                "skp_flash_attn_fwd_f32")
+        if FLASH_SPLIT and flash_split_ok(B, Bk, heads, Nq, Nk, C // heads):
+            _flash_fwd_split(q, k, v, out, lse, heads, float(scale))
+        else:
+            N.check(N.lib().skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                   B, Bk, heads, Nq, Nk, C // heads, float(scale), _stream()),
+                    "skp_flash_attn_fwd_f32")
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.meta = (heads, float(scale))
         return out

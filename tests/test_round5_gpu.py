@@ -186,3 +186,48 @@ def test_split_bf16_winograd_conv_statistics_and_gate():
     assert lib.skp_conv3x3_f4s_ok(1, 16, 32, 8, 8) == 0 and lib.skp_conv3x3_f4s_ok(1, 24, 64, 8, 8) == 0 and lib.skp_conv3x3_f4s_ok(1, 16, 64, 6, 8) == 0
     rc = lib.skp_conv3x3_f4s_f32(x.data_ptr(), ops._wino4s_filters(w, False).data_ptr(), None, None, y.data_ptr(), None, None, 1, 16, 32, 8, 8, None)
     assert rc == N.lib().skp_conv3x3_f4s_f32(x.data_ptr(), ops._wino4s_filters(w, False).data_ptr(), None, None, y.data_ptr(), None, None, 1, 16, 32, 8, 8, None) != 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flash attention forward on the bf16 matrix cores with three-term operand splits (csrc/skp_flash_attn_s.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Bk,H,N,Nk,d", [
+    (2, 2, 8, 1024, 1024, 40),        # self-attention, the 64^2-layer head size (row sums through the spare row of O^T)
+    (1, 1, 4, 300, 200, 40),          # ragged query block and ragged last key tile
+    (3, 1, 2, 64, 500, 40),           # one k / v shared by all rows (cross-attention with many tokens)
+    (2, 2, 8, 1024, 1024, 80),        # d % 16 == 0: VALU row sums, the full 160 KB of LDS
+    (1, 1, 3, 100, 77, 80),           # a single ragged tile
+])
+def test_split_bf16_flash_attention_forward_vs_fp64(B, Bk, H, N, Nk, d):
+    """skp_flash_attn_fwd_split_f32 against fp64 softmax(scale q k^T) v and against the fp32-instruction kernel on the same
+    inputs: out and lse; error at most 1.5x the fp32 kernel's (+ 1e-7 of the scale); a spiked key (one logit far above the
+    rest in the middle of the key axis) exercises the running-max rescale; deterministic."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(9)
+    C = H * d
+    q = torch.randn(B, N, C, generator=g)
+    k = torch.randn(Bk, Nk, C, generator=g)
+    v = torch.randn(Bk, Nk, C, generator=g)
+    k[:, Nk // 2] *= 6.0                                                          # the spike
+    scale = d ** -0.5
+    qd = q.double().reshape(B, N, H, d).permute(0, 2, 1, 3)
+    kd = k.double().reshape(Bk, Nk, H, d).permute(0, 2, 1, 3).expand(B, H, Nk, d)
+    vd = v.double().reshape(Bk, Nk, H, d).permute(0, 2, 1, 3).expand(B, H, Nk, d)
+    sc = qd @ kd.transpose(-1, -2) * scale
+    ref = (sc.softmax(-1) @ vd).permute(0, 2, 1, 3).reshape(B, N, C)
+    ref_lse = torch.logsumexp(sc, dim=-1)
+    assert ops.N.lib().skp_flash_attn_fwd_split_ok(B, Bk, H, N, Nk, d) == 1
+    qg, kg, vg = q.cuda(), k.cuda(), v.cuda()
+    out, lse = ops.flash_attn_fwd_split(qg, kg, vg, H, scale)
+    o32 = torch.empty_like(qg); l32 = torch.empty(B, H, N, device="cuda")
+    ops.N.check(ops.N.lib().skp_flash_attn_fwd_f32(qg.data_ptr(), kg.data_ptr(), vg.data_ptr(), o32.data_ptr(), l32.data_ptr(),
+                                                   B, Bk, H, N, Nk, d, float(scale), ops._stream()), "fp32 flash forward")
+    sref = ref.abs().max().item()
+    e_s, e_32 = (out.cpu().double() - ref).abs().max().item() / sref, (o32.cpu().double() - ref).abs().max().item() / sref
+    el_s, el_32 = (lse.cpu().double() - ref_lse).abs().max().item(), (l32.cpu().double() - ref_lse).abs().max().item()
+    print(f"d={d} N={N} Nk={Nk}: out err split {e_s:.2e} fp32 {e_32:.2e} (ratio {e_s / e_32:.2f}); lse err split {el_s:.2e} fp32 {el_32:.2e}")
+    assert e_s <= 1.5 * e_32 + 1e-7 and e_s < 2e-6
+    assert el_s <= 1.5 * el_32 + 2e-6
+    out2, lse2 = ops.flash_attn_fwd_split(qg, kg, vg, H, scale)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    assert ops.N.lib().skp_flash_attn_fwd_split_ok(1, 1, 8, 64, 64, 64) == 0      # head sizes without a split kernel stay on fp32
