@@ -255,6 +255,40 @@ def split_conv_probe(ops, B, image_size, iters, device):
             "on_path_of_record": False, "status": "measured negative (target was >= 1.4x): stage accounting in profiles/r05_conv_split.md"}
 
 
+def split_flash_probe(ops, B, iters, device):
+    """The flash-attention forward of the 64^2 layers (N = 4096, 8 heads x 40) on the bf16 matrix cores with three-term operand
+    splits (csrc/skp_flash_attn_s.hip, its K / V pre-pass included) next to the fp32-instruction forward, and both errors against
+    an fp64 reference on one (row, head)."""
+    g = torch.Generator(device="cpu").manual_seed(4)
+    H, N, d = 8, 4096, 40
+    q, k, v = (torch.randn(B, N, H * d, generator=g).to(device) for _ in range(3))
+    scale = d ** -0.5
+    o32 = torch.empty_like(q); l32 = torch.empty(B, H, N, device=device)
+    lib, Nn = ops.N.lib(), ops.N
+    f32 = lambda: Nn.check(lib.skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o32.data_ptr(), l32.data_ptr(), B, B, H, N, N, d,
+                                                      float(scale), ops._stream()), "fp32 flash forward")
+    spl = lambda: ops.flash_attn_fwd_split(q, k, v, H, scale)
+    for _ in range(3):
+        f32(); spl()
+    times = {"f32": [], "split": []}
+    for _ in range(3):
+        for name, fn in (("f32", f32), ("split", spl)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            times[name].append(e0.elapsed_time(e1) / iters * 1e3)
+    ref = ((q[0, :, :d].double() @ k[0, :, :d].double().T) * scale).softmax(-1) @ v[0, :, :d].double()
+    f32(); os_, _ = spl()
+    e32 = (o32[0, :, :d].double() - ref).abs().max().item(); esp = (os_[0, :, :d].double() - ref).abs().max().item()
+    t32, tsp = sorted(times["f32"])[1], sorted(times["split"])[1]
+    return {"what": f"flash attention forward, N = {N}, {H} heads x {d}, {B} rows: fp32-instruction kernel vs the split-bf16 kernel (pre-pass included)",
+            "fp32_kernel_us": t32, "split_kernel_us": tsp, "speedup": t32 / tsp, "max_err_vs_fp64_ratio": esp / e32,
+            "max_err_vs_fp64": {"fp32_kernel": e32, "split_kernel": esp},
+            "split_tflops_equiv": 4.0 * N * N * d * B * H / tsp / 1e6}
+
+
 def conv_step_forms(ops, B, image_size, iters, device):
     """The same kernel in the forms and at the launch shapes the step actually runs (micro-timed like conv_roofline): the
     first-level VAE convolutions carry the GroupNorm + SiLU of their input in the patch load and leave block statistics
@@ -685,11 +719,37 @@ def main():
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(10, a.kernel_iters // 3), dev)
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows, cv_folded = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         cv_forms = conv_step_forms(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
-        try:
-            f32_split = split_conv_probe(ops, B, min(image_size, 512), max(5, a.kernel_iters // 6), dev) if a.model.startswith("sd") else None
-        except Exception as e:                                    # noqa: BLE001 -- an experiment key never takes the line of record down
-            print(f"bench.py: split-conv probe unavailable ({e})", file=sys.stderr)
-            f32_split = None
+        f32_split = None
+        if a.model.startswith("sd") and world == 1:
+            # EXPERIMENT beside the line of record (never part of `value`): fp32-accurate matrix products on the bf16 matrix
+            # cores by three-term operand splits.  (1) the step with the flash-attention forward routed through the split kernel
+            # (the one kernel family where the split pays), timed like the line of record; (2) the two split kernels next to
+            # their fp32-instruction counterparts on this box.
+            try:
+                ops.FLASH_SPLIT = True
+                for _ in range(2):
+                    one_step()
+                torch.cuda.synchronize()
+                t0s = time.perf_counter()
+                for _ in range(a.steps):
+                    one_step()
+                torch.cuda.synchronize()
+                el_s = time.perf_counter() - t0s
+                ops.FLASH_SPLIT = False
+                fa_probe = split_flash_probe(ops, B, max(5, a.kernel_iters // 6), dev)
+                cv_probe = split_conv_probe(ops, B, min(image_size, 512), max(5, a.kernel_iters // 6), dev)
+                f32_split = {"value": global_batch * a.steps / el_s, "ms_per_step": el_s / a.steps * 1e3, "unit": "images/sec",
+                             "dtype": "f32 via 3 x bf16 operand split (6 products), fp32 accumulate",
+                             "what": "the same step with the flash-attention FORWARD of the d = 40 / 80 self-attention layers on "
+                                     "the split kernel (SKP_FLASH_SPLIT=1); everything else, incl. the attention backward and the "
+                                     "convolutions, on the fp32 instructions",
+                             "max_err_vs_fp64_ratio": fa_probe["max_err_vs_fp64_ratio"],
+                             "flash_forward": fa_probe, "conv3x3": cv_probe,
+                             "on_path_of_record": False}
+            except Exception as e:                                # noqa: BLE001 -- an experiment key never takes the line of record down
+                ops.FLASH_SPLIT = False
+                print(f"bench.py: f32_split experiment unavailable ({e})", file=sys.stderr)
+                f32_split = None
         def local_step():                                        # rank 0 only: the step without its collective
             nonlocal cursor
             idx = [(cursor + i) % len(data) for i in range(per_rank)]

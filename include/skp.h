@@ -221,6 +221,14 @@ int skp_flash_attn_fwd_split_ok(int B, int Bk, int H, int N, int Nk, int d);
 int64_t skp_flash_attn_fwd_split_workspace(int B, int Bk, int H, int N, int Nk, int d);
 int skp_flash_attn_fwd_split_f32(const float* q, const float* k, const float* v, float* out, float* lse, void* workspace,
                                  int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream);
+/* Its backward for the self-attention shapes (Bk == B, Nk == N, d == 40: the 64^2 layers): dq, dk, dv as skp_flash_attn_bwd_f32
+ * from (q, k, v, out, dout, lse); two kernels (dQ: lane = query; dK / dV: lane = key), seven tile products on the split
+ * tuples, D = rowsum(dout * out) computed on the way.  workspace: skp_flash_attn_bwd_split_workspace() bytes, REQUIRED. */
+int skp_flash_attn_bwd_split_ok(int B, int Bk, int H, int N, int Nk, int d);
+int64_t skp_flash_attn_bwd_split_workspace(int B, int Bk, int H, int N, int Nk, int d);
+int skp_flash_attn_bwd_split_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                 const float* lse, float* dq, float* dk, float* dv, void* workspace, int B, int Bk, int H, int N,
+                                 int Nk, int d, float scale, void* stream);
 
 /* Flash-style self-attention (ptp_utils.py:493-506 with context = x) for the long image-token sequences: fp32 MFMA,
  * 64-key tiles in LDS, online softmax; the [B*h,N,N] scores are never materialised.

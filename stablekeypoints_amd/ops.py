@@ -651,6 +651,23 @@ def _flash_fwd_split(q, k, v, out, lse, heads, scale):
                                                  B, Bk, heads, Nq, Nk, C // heads, scale, _stream()), "skp_flash_attn_fwd_split_f32")
 
 
+def _flash_bwd_split(q, k, v, out, dout, lse, dq, dk, dv, heads, scale):
+    B, Nq, C = q.shape
+    nbytes = N.lib().skp_flash_attn_bwd_split_workspace(B, B, heads, Nq, Nq, C // heads)
+    ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+    N.check(N.lib().skp_flash_attn_bwd_split_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, B, heads, Nq, Nq, C // heads,
+                                                 float(scale), _stream()), "skp_flash_attn_bwd_split_f32")
+
+
+def flash_attn_bwd_split(q, k, v, out, dout, lse, heads: int, scale: float):
+    """Direct entry (tests / tools): (dq, dk, dv) of the split backward (self-attention shapes)."""
+    q, k, v, out, dout, lse = (_dev(t_, "t") for t_ in (q, k, v, out, dout, lse))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _flash_bwd_split(q, k, v, out, dout, lse, dq, dk, dv, heads, scale)
+    return dq, dk, dv
+
+
 def flash_attn_fwd_split(q, k, v, heads: int, scale: float):
     """Direct entry (tests / tools): (out, lse) of the split forward."""
     q, k, v = _dev(q, "q"), _dev(k, "k"), _dev(v, "v")
@@ -691,6 +708,9 @@ class FlashAttnFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dk = torch.empty(B, Nk, C, device=q.device, dtype=torch.float32)
         dv = torch.empty_like(dk)
+        if FLASH_SPLIT and Nk >= FLASH_SPLIT_MIN_KEYS and N.lib().skp_flash_attn_bwd_split_ok(B, Bk, heads, Nq, Nk, C // heads):
+            _flash_bwd_split(q, k, v, out, dout, lse, dq, dk, dv, heads, scale)
+            return dq, dk, dv, None, None
         nbytes = N.lib().skp_flash_attn_bwd_workspace(B, Bk, heads, Nq, Nk, C // heads)
         if nbytes < 0:
             N.check(int(nbytes), "skp_flash_attn_bwd_workspace")

@@ -231,3 +231,48 @@ def test_split_bf16_flash_attention_forward_vs_fp64(B, Bk, H, N, Nk, d):
     out2, lse2 = ops.flash_attn_fwd_split(qg, kg, vg, H, scale)
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
     assert ops.N.lib().skp_flash_attn_fwd_split_ok(1, 1, 8, 64, 64, 64) == 0      # head sizes without a split kernel stay on fp32
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 8, 1024), (1, 3, 300), (1, 2, 77)])
+def test_split_bf16_flash_attention_backward_vs_fp64(B, H, N):
+    """skp_flash_attn_bwd_split_f32 (d = 40 self-attention: dQ kernel + dK / dV kernel on three-term bf16 tuples) against fp64
+    autograd through softmax(scale q k^T) v and against the fp32-instruction backward on the same inputs (ragged query / key
+    tiles included); each gradient's error at most 1.5x the fp32 kernels' (+ 1e-7 of its scale); deterministic."""
+    from stablekeypoints_amd import ops
+    d = 40
+    g = torch.Generator().manual_seed(19)
+    C = H * d
+    q, k, v, go = (torch.randn(B, N, C, generator=g) for _ in range(4))
+    k[:, N // 3] *= 5.0
+    scale = d ** -0.5
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    def heads(t):
+        return t.reshape(B, N, H, d).permute(0, 2, 1, 3)
+    ref = ((heads(qd) @ heads(kd).transpose(-1, -2) * scale).softmax(-1) @ heads(vd)).permute(0, 2, 1, 3).reshape(B, N, C)
+    (ref * go.double()).sum().backward()
+    assert ops.N.lib().skp_flash_attn_bwd_split_ok(B, B, H, N, N, d) == 1
+    qg, kg, vg, gg = q.cuda(), k.cuda(), v.cuda(), go.cuda()
+    out, lse = ops.flash_attn_fwd_split(qg, kg, vg, H, scale)
+    dq, dk, dv = ops.flash_attn_bwd_split(qg, kg, vg, out, gg, lse, H, scale)
+    q32 = qg.clone().requires_grad_(True); k32 = kg.clone().requires_grad_(True); v32 = vg.clone().requires_grad_(True)
+    prev, ops.FLASH_SPLIT = ops.FLASH_SPLIT, False
+    try:
+        (ops.self_attention(q32, k32, v32, H, scale) * gg).sum().backward()
+    finally:
+        ops.FLASH_SPLIT = prev
+    for name, got, g32, refg in (("dq", dq, q32.grad, qd.grad), ("dk", dk, k32.grad, kd.grad), ("dv", dv, v32.grad, vd.grad)):
+        sc = refg.abs().max().item()
+        e_s, e_32 = (got.cpu().double() - refg).abs().max().item() / sc, (g32.cpu().double() - refg).abs().max().item() / sc
+        print(f"N={N} {name}: split {e_s:.2e}  fp32 kernels {e_32:.2e}  ratio {e_s / e_32:.2f}")
+        assert e_s <= 1.5 * e_32 + 1e-7 and e_s < 5e-6
+    dq2, dk2, dv2 = ops.flash_attn_bwd_split(qg, kg, vg, out, gg, lse, H, scale)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    # through autograd with the switch on: the same kernels
+    prev, ops.FLASH_SPLIT, pmin = ops.FLASH_SPLIT, True, ops.FLASH_SPLIT_MIN_KEYS
+    ops.FLASH_SPLIT_MIN_KEYS = 1
+    try:
+        qa = qg.clone().requires_grad_(True); ka = kg.clone().requires_grad_(True); va = vg.clone().requires_grad_(True)
+        (ops.self_attention(qa, ka, va, H, scale) * gg).sum().backward()
+    finally:
+        ops.FLASH_SPLIT, ops.FLASH_SPLIT_MIN_KEYS = prev, pmin
+    assert torch.equal(qa.grad, dq) and torch.equal(ka.grad, dk) and torch.equal(va.grad, dv)

@@ -41,3 +41,29 @@ for name, B, H, N, d in (("64^2 layer, 8 rows, d=40", 8, 8, 4096, 40), ("64^2 la
     print(f"{name:36s} f32 {t32[2]:8.1f} us {row['f32_tf']:6.1f} TF/s | split {tsp[2]:8.1f} us {row['split_tf_equiv']:6.1f} TF/s-eq | x{row['speedup']:.2f} | err {e32:.2e} / {esp:.2e} ({row['err_ratio']:.2f}x)", flush=True)
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)
+
+# ---- backward at d = 40 (the 64^2 layers): split (images + dQ kernel + dK/dV kernel) vs the fp32-instruction backward ----
+for name, B, H, N, d in (("bwd 64^2 layer, 8 rows, d=40", 8, 8, 4096, 40), ("bwd 64^2 layer, 2 rows, d=40", 2, 8, 4096, 40)):
+    g = torch.Generator().manual_seed(1)
+    C = H * d
+    q, k, v, go = (torch.randn(B, N, C, generator=g).cuda() for _ in range(4))
+    scale = d ** -0.5
+    out, lse = ops.flash_attn_fwd_split(q, k, v, H, scale)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    nb = ops.N.lib().skp_flash_attn_bwd_workspace(B, B, H, N, N, d)
+    ws = torch.empty(nb // 4, device="cuda")
+    f32 = lambda: ops.N.check(ops.N.lib().skp_flash_attn_bwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), go.data_ptr(), lse.data_ptr(),
+                                                                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, B, H, N, N, d, float(scale),
+                                                                  ops._stream()), "f32 bwd")
+    spl = lambda: ops.flash_attn_bwd_split(q, k, v, out, go, lse, H, scale)
+    for _ in range(3): f32(); spl()
+    t32, tsp = [], []
+    for _ in range(5):
+        t32.append(timeit(f32, 5)); tsp.append(timeit(spl, 5))
+    t32.sort(); tsp.sort()
+    fl = 10.0 * N * N * d * B * H / 1e6                         # 2.5 x the forward's FLOPs
+    row = dict(shape=name, B=B, H=H, N=N, d=d, f32_us=t32[2], split_us=tsp[2], speedup=t32[2] / tsp[2], f32_tf=fl / t32[2], split_tf_equiv=fl / tsp[2])
+    rows.append(row)
+    print(f"{name:36s} f32 {t32[2]:8.1f} us {row['f32_tf']:6.1f} TF/s | split {tsp[2]:8.1f} us {row['split_tf_equiv']:6.1f} TF/s-eq | x{row['speedup']:.2f}", flush=True)
+if len(sys.argv) > 1:
+    json.dump(rows, open(sys.argv[1], "w"), indent=1)
