@@ -211,6 +211,12 @@ int skp_flash_attn_fwd_f32(const float* q, const float* k, const float* v, float
 int skp_flash_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
                            const float* lse, float* dq, float* dk, float* dv, float* workspace,
                            int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream);
+/* _bwd_ld: dq, dk, dv are column bands of wider row-major buffers, row stride `ldg` floats (>= H*d, a multiple of 4): the three
+ * gradients of a self-attention block written side by side into one [B*N, 3*H*d] buffer make the input gradient of its frozen
+ * q / k / v projections (ptp_utils.py:513-520) a single GEMM.  d in {40,64,80,160}; SKP_E_RANGE for the other head sizes. */
+int skp_flash_attn_bwd_ld_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                              const float* lse, float* dq, float* dk, float* dv, float* workspace,
+                              int B, int Bk, int H, int N, int Nk, int d, float scale, int ldg, void* stream);
 
 /* The flash-attention FORWARD on the BF16 matrix cores with three-term operand splits (skp_flash_attn_s.hip; same role and
  * contract as skp_flash_attn_fwd_f32: out, natural-log lse for the fp32 backward kernels): fp32 in / out, fp32 softmax and

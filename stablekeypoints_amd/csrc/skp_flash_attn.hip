@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
                                                                    const float* __restrict__ v, const float* __restrict__ out,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
                                                                    float* __restrict__ dq, float* __restrict__ Dbuf, int H, int N,
-                                                                   int Nk, int kvb, float scale) {
+                                                                   int Nk, int kvb, float scale, int ldg) {
     using F = FA2<D>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
     for (int nt = 0; nt < NQT; ++nt) {
         const int n = nrow[nt];
         if (n < N) {
-            float* drow = dq + ((size_t)b * N + n) * C + h * D;
+            float* drow = dq + ((size_t)b * N + n) * ldg + h * D;      // ldg: row stride of the gradient outputs
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
                                                                     const float* __restrict__ v, const float* __restrict__ dout,
                                                                     const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                     float* __restrict__ dk, float* __restrict__ dv, int H, int N,
-                                                                    int Nk, int kvb, float scale) {
+                                                                    int Nk, int kvb, float scale, int ldg) {
     using F = FA2<D>;
     constexpr int BUF = 2 * F::TILE + 2 * F::KT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
     for (int tt = 0; tt < NTT; ++tt) {
         const int t = trow[tt];
         if (t < Nk) {
-            const size_t ro = ((size_t)b * Nk + t) * C + h * D;
+            const size_t ro = ((size_t)b * Nk + t) * ldg + h * D;
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
                                                                    const float* __restrict__ v, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqp, float* __restrict__ dk,
-                                                                   float* __restrict__ dv, int H, int N, int Nk, float scale) {
+                                                                   float* __restrict__ dv, int H, int N, int Nk, float scale, int ldg) {
     using F = FA2<D>;
     using X = FA2F<D, OVL, NQ>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
     for (int tt = 0; tt < TT; ++tt) {
         const int t = trow[tt];
         if (t < Nk) {
-            const size_t ro = ((size_t)b * Nk + t) * C + h * D;
+            const size_t ro = ((size_t)b * Nk + t) * ldg + h * D;
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
@@ -812,13 +812,15 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
 }
 
 // dq = scale * sum_kb part[kb]   (fixed order)
+// (c4 = float4 per row of the partials, ldg4 = float4 per row of dq: equal unless dq is a column band of a wider buffer)
 __global__ __launch_bounds__(256) void skp_fa2_dq_reduce_kernel(const float* __restrict__ part, float* __restrict__ dq, long n4,
-                                                               long stride, int nkb, float scale) {
+                                                               long stride, int nkb, float scale, int c4, int ldg4) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 acc = ((const f32x4*)part)[i];
     for (int z = 1; z < nkb; ++z) acc += ((const f32x4*)(part + (size_t)z * stride))[i];
-    ((f32x4*)dq)[i] = acc * scale;
+    const long o = c4 == ldg4 ? i : (i / c4) * ldg4 + (i % c4);
+    ((f32x4*)dq)[o] = acc * scale;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -876,7 +878,7 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
 template <int D, int NQ, int MINWQ, int NT, int MINWT, bool PRE>
 static int fa2_launch_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                           const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk, int kvb,
-                          float scale, hipStream_t st) {
+                          float scale, int ldg, hipStream_t st) {
     using F = FA2<D>;
     const size_t lds_q = (size_t)4 * F::TILE * sizeof(float), lds_kv = (size_t)2 * (2 * F::TILE + 2 * F::KT) * sizeof(float);
     static bool attr = false;
@@ -889,11 +891,11 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
     }
     dim3 block(256);
     hipLaunchKernelGGL((skp_fa2_bwd_dq_kernel<D, NQ, MINWQ, PRE>), dim3((N + 64 * NQ - 1) / (64 * NQ), H, B), block, lds_q, st,
-                       q, k, v, out, dout, lse, dq, ws, H, N, Nk, kvb, scale);
+                       q, k, v, out, dout, lse, dq, ws, H, N, Nk, kvb, scale, ldg);
     int rc = skp_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL((skp_fa2_bwd_dkv_kernel<D, NT, MINWT, PRE>), dim3((Nk + 64 * NT - 1) / (64 * NT), H, B), block, lds_kv, st,
-                       q, k, v, dout, lse, ws, dk, dv, H, N, Nk, kvb, scale);
+                       q, k, v, dout, lse, ws, dk, dv, H, N, Nk, kvb, scale, ldg);
     return skp_launch_status();
 }
 
@@ -920,7 +922,7 @@ int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
 template <int D, int MINB, bool OVL, int NQ, int NW = 4>
 static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                 const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk,
-                                float scale, hipStream_t st) {
+                                float scale, int ldg, hipStream_t st) {
     using X = FA2F<D, OVL, NQ>;
     const size_t lds = (size_t)X::LDS_FLOATS * sizeof(float);
     static bool attr = false;
@@ -937,36 +939,36 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     if (rc) return rc;
     const int nkb = (Nk + X::KB - 1) / X::KB;
     hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ, NW>), dim3(nkb, H, B), dim3(64 * NW), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
-                       N, Nk, scale);
+                       N, Nk, scale, ldg);
     rc = skp_launch_status();
     if (rc) return rc;
     const long n4 = (long)B * N * H * D / 4;
     hipLaunchKernelGGL(skp_fa2_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, dq, n4,
-                       (long)B * N * H * D, nkb, scale);
+                       (long)B * N * H * D, nkb, scale, H * D / 4, ldg / 4);
     return skp_launch_status();
 }
 
 // workspace: skp_fa2_bwd_workspace() bytes; -100 when the head size is not built here
 int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
                 float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d, float scale,
-                int allow_fused, void* stream) {
+                int allow_fused, int ldg, void* stream) {
     const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
     const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
     const int variant = ev ? atoi(ev) : 0;
     if (allow_fused && fa2_fused_ok(Bk, B, H, N, Nk, d)) {
-        if (d == 40) return fa2_launch_bwd_fused<40, 2, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
-        if (d == 64) return fa2_launch_bwd_fused<64, 2, true, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+        if (d == 40) return fa2_launch_bwd_fused<40, 2, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
+        if (d == 64) return fa2_launch_bwd_fused<64, 2, true, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
         // 80-wide heads: 64-query tiles on EIGHT waves (16 keys each: half the K / V fragments and dK / dV accumulators per wave,
         // 224 registers, nothing spilled, two waves per SIMD at one 120 KB workgroup per CU).  SKP_FA2_D80=3: the 48-query
         // four-wave form of round 2 (two workgroups per CU, 57 spilled registers), =1: 64 queries on four waves (one per SIMD)
         { const char* e8 = getenv("SKP_FA2_D80");
-          if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
-          if (e8 && e8[0] == '3') return fa2_launch_bwd_fused<80, 2, true, 3>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st); }
-        return fa2_launch_bwd_fused<80, 1, false, 4, 8>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, st);
+          if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
+          if (e8 && e8[0] == '3') return fa2_launch_bwd_fused<80, 2, true, 3>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st); }
+        return fa2_launch_bwd_fused<80, 1, false, 4, 8>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
     }
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
-    return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, st)
+    return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, ldg, st)
     switch (d) {
         case 40:
             if (variant == 1) FA2_BWD(40, 1, 3, 1, 3, true);

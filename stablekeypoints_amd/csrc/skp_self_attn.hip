@@ -251,7 +251,7 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
                 int Nk, int d, float scale, void* stream);
 int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
                 float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
-                float scale, int allow_fused, void* stream);
+                float scale, int allow_fused, int ldg, void* stream);
 
 int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d);
 
@@ -292,26 +292,38 @@ extern "C" int64_t skp_flash_attn_bwd_workspace(int B, int Bk, int H, int N, int
 
 static int flash_bwd_impl(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
                           float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
-                          float scale, int allow_fused, void* stream);
+                          float scale, int allow_fused, int ldg, void* stream);
 
 /* workspace: skp_flash_attn_bwd_workspace() bytes */
 extern "C" int skp_flash_attn_bwd_f32(const float* q, const float* k, const float* v, const float* out,
                                       const float* dout, const float* lse, float* dq, float* dk, float* dv,
                                       float* workspace, int B, int Bk, int H, int N, int Nk, int d, float scale,
                                       void* stream) {
-    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, 1, stream);
+    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, 1, H * d, stream);
+}
+
+/* the same with dq, dk, dv as column bands of wider row-major buffers: row stride `ldg` floats (>= H*d, multiple of 4) -- the three
+ * gradients of a self-attention block land side by side in one [B*N, 3*H*d] buffer, which makes the input gradient of its
+ * frozen q / k / v projections ONE GEMM over the concatenated weights.  Second-generation head sizes only. */
+extern "C" int skp_flash_attn_bwd_ld_f32(const float* q, const float* k, const float* v, const float* out,
+                                         const float* dout, const float* lse, float* dq, float* dk, float* dv,
+                                         float* workspace, int B, int Bk, int H, int N, int Nk, int d, float scale, int ldg,
+                                         void* stream) {
+    if (ldg < H * d || (ldg & 3)) return SKP_E_BADARG;
+    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, 1, ldg, stream);
 }
 
 static int flash_bwd_impl(const float* q, const float* k, const float* v, const float* out, const float* dout, const float* lse,
                           float* dq, float* dk, float* dv, float* workspace, int B, int Bk, int H, int N, int Nk, int d,
-                          float scale, int allow_fused, void* stream) {
+                          float scale, int allow_fused, int ldg, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return SKP_E_BADARG;
     int rc = sa_check(B, Bk, H, N, Nk, d);
     if (rc) return rc;
     if (!sa_gen1()) {
-        rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, allow_fused, stream);
+        rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, allow_fused, ldg, stream);
         if (rc != -100) return rc;
     }
+    if (ldg != H * d) return SKP_E_RANGE;                        // the first-generation kernels write dense rows only
     const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
     {
@@ -350,5 +362,5 @@ extern "C" int skp_self_attn_bwd_f32(const float* q, const float* k, const float
                                      const float* dout, const float* lse, float* dq, float* dk, float* dv,
                                      float* workspace, int B, int H, int N, int d, float scale, void* stream) {
     // B*H*N-float workspace contract of this entry point: the two-kernel form only
-    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, B, H, N, N, d, scale, 0, stream);
+    return flash_bwd_impl(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, B, H, N, N, d, scale, 0, H * d, stream);
 }

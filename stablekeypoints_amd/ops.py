@@ -1256,16 +1256,51 @@ def linear_auto(x, weight, bias=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+_QKV_CACHE = {}
+
+
+def _qkv_stack(wq, wk, wv):
+    """[3, C, C] stack of the three frozen projection weights of a self-attention block (made once per block; checked
+    against the parameters' versions and identities like the other derived buffers of frozen weights)."""
+    import weakref
+    key = (wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), tuple(wq.shape), wq.device)
+    hit = _QKV_CACHE.get(key)
+    ver = (wq._version, wk._version, wv._version)
+    if hit is not None and hit[0] == ver and hit[2]() is wq:
+        return hit[1]
+    w3 = torch.stack([wq.detach(), wk.detach(), wv.detach()]).contiguous()
+    _QKV_CACHE[key] = (ver, w3, weakref.ref(wq))
+    return w3
+
+
+QKV_STACKED = os.environ.get("SKP_QKV_STACKED", "1") != "0"   # A/B switch: one batched GEMM with a broadcast A operand
+
+
+def _qkv_forward(x, wq, wk, wv):
+    """q, k, v as ONE strided-batched GEMM: A = x with batch stride 0, B_i = W_i^T, C = [3, M, C] -- three times the
+    workgroups of a single projection in one launch and three contiguous outputs (no strided views for the attention
+    kernels).  Bit-equal to three F.linear calls per library kernel choice; 8 rows: 220 -> 180 us at 64^2, 186 -> 165 us
+    at 16^2, 2 rows: 79 -> 49 us (tools/qkv_probe.py)."""
+    F = torch.nn.functional
+    if not (QKV_STACKED and x.is_cuda and wq.shape == wk.shape == wv.shape):
+        return F.linear(x, wq), F.linear(x, wk), F.linear(x, wv)
+    c_in, c_out = wq.shape[1], wq.shape[0]
+    x2 = x.reshape(-1, c_in)
+    m = x2.shape[0]
+    out = torch.bmm(x2.unsqueeze(0).expand(3, m, c_in), _qkv_stack(wq, wk, wv).transpose(1, 2))
+    shp = (*x.shape[:-1], c_out)
+    return out[0].view(shp), out[1].view(shp), out[2].view(shp)
+
+
 class QKVProjFn(torch.autograd.Function):
     """q, k, v = x.Wq^T, x.Wk^T, x.Wv^T of a frozen self-attention block (bias-free projections, ptp_utils.py:513-520).
-    The input gradient accumulates inside the GEMMs (dx = dq.Wq, then two beta = 1 GEMMs) instead of three GEMMs and two
-    add passes over [B, N, C]."""
+    Forward: one batched GEMM (_qkv_forward).  The input gradient accumulates inside the GEMMs (dx = dq.Wq, then two
+    beta = 1 GEMMs) instead of three GEMMs and two add passes over [B, N, C]."""
 
     @staticmethod
     def forward(ctx, x, wq, wk, wv):
         ctx.save_for_backward(wq, wk, wv)
-        F = torch.nn.functional
-        return F.linear(x, wq), F.linear(x, wk), F.linear(x, wv)
+        return _qkv_forward(x, wq, wk, wv)
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
@@ -1282,10 +1317,66 @@ QKV_ACCUM = os.environ.get("SKP_QKV_ACCUM", "1") != "0"       # A/B switch
 
 def qkv_proj(x, wq, wk, wv):
     """Self-attention projections; frozen bias-free weights take the accumulate-in-GEMM backward."""
-    if QKV_ACCUM and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and not (wq.requires_grad or wk.requires_grad or wv.requires_grad):
+    frozen = not (wq.requires_grad or wk.requires_grad or wv.requires_grad)
+    if QKV_ACCUM and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and frozen:
         return QKVProjFn.apply(x, wq, wk, wv)
+    if frozen and not (x.requires_grad and torch.is_grad_enabled()):
+        return _qkv_forward(x, wq, wk, wv)
     F = torch.nn.functional
     return F.linear(x, wq), F.linear(x, wk), F.linear(x, wv)
+
+
+class SelfAttnQKVFn(torch.autograd.Function):
+    """One self-attention block core with frozen bias-free projections (ptp_utils.py:513-520, 493-506, 540):
+    out = merge_heads(softmax(scale q k^T) v), q | k | v = x.W^T as one batched GEMM.  Backward: the flash backward writes
+    dq, dk, dv as column bands of ONE [B*N, 3C] buffer (skp_flash_attn_bwd_ld_f32), so dx is a single GEMM against the
+    stacked weights [3C, C] instead of three accumulating ones (8 rows: 224 -> 174 us at 64^2, tools/qkv_probe.py)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, heads, scale):
+        q, k, v = _qkv_forward(x, wq, wk, wv)
+        B, Nq, C = q.shape
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
+        N.check(N.lib().skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                               B, B, heads, Nq, Nq, C // heads, float(scale), _stream()), "skp_flash_attn_fwd_f32")
+        ctx.save_for_backward(q, k, v, out, lse, wq, wk, wv)
+        ctx.meta = (int(heads), float(scale), tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, wq, wk, wv = ctx.saved_tensors
+        heads, scale, xshape = ctx.meta
+        dout = _dev(dout, "dout")
+        B, Nq, C = q.shape
+        d3 = torch.empty(B * Nq, 3 * C, device=q.device, dtype=torch.float32)
+        nbytes = N.lib().skp_flash_attn_bwd_workspace(B, B, heads, Nq, Nq, C // heads)
+        if nbytes < 0:
+            N.check(int(nbytes), "skp_flash_attn_bwd_workspace")
+        ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+        p = d3.data_ptr()
+        N.check(N.lib().skp_flash_attn_bwd_ld_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                                  lse.data_ptr(), p, p + 4 * C, p + 8 * C, ws.data_ptr(), B, B, heads, Nq, Nq,
+                                                  C // heads, scale, 3 * C, _stream()), "skp_flash_attn_bwd_ld_f32")
+        dx = torch.mm(d3, _qkv_stack(wq, wk, wv).view(3 * C, wq.shape[1]))
+        return dx.view(xshape), None, None, None, None, None
+
+
+FA2_HEAD_DIMS = (40, 64, 80, 160)          # head sizes of the second-generation flash kernels (the *_ld entry serves these)
+
+
+def self_attention_block(x, wq, wk, wv, heads: int, scale: float):
+    """Self-attention core of a block whose q / k / v projections are frozen and bias-free: projections + attention, with
+    the fused input gradient where the kernels serve the head size; the composition of `qkv_proj` and `self_attention`
+    otherwise (no gradient wanted, split-bf16 experiment switched on, other head sizes)."""
+    frozen = not (wq.requires_grad or wk.requires_grad or wv.requires_grad)
+    if (QKV_STACKED and QKV_ACCUM and not FLASH_SPLIT and x.is_cuda and x.dim() == 3 and frozen and x.requires_grad
+            and torch.is_grad_enabled() and wq.shape == wk.shape == wv.shape and wq.shape[0] % heads == 0
+            and (wq.shape[0] // heads) in FA2_HEAD_DIMS and not os.environ.get("SKP_FLASH_GEN", "") == "1"):
+        return SelfAttnQKVFn.apply(_dev(x, "x"), wq, wk, wv, int(heads), float(scale))
+    q, k, v = qkv_proj(x, wq, wk, wv)
+    return self_attention(q, k, v, heads, scale)
 
 
 def conv1x1_nobias(x, weight):

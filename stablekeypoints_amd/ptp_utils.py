@@ -134,6 +134,9 @@ def register_attention_control(model, controller, feature_upsample_res=256):
                 raise StopForward()
             if (not is_cross) and self.to_q.bias is None and self.to_k.bias is None and self.to_v.bias is None \
                     and "forward" not in self.to_q.__dict__:
+                if x.is_cuda and ops.self_attn_supported(dim, self.heads):
+                    return to_out(ops.self_attention_block(x, self.to_q.weight, self.to_k.weight, self.to_v.weight,
+                                                           self.heads, self.scale))
                 q, k, v = ops.qkv_proj(x, self.to_q.weight, self.to_k.weight, self.to_v.weight)
             else:
                 q = self.to_q(x)
@@ -198,6 +201,12 @@ def accelerate_cross_attention(net):
                 def forward(x, context=None, mask=None):
                     is_cross = context is not None
                     ctx = context if is_cross else x
+                    if (not is_cross) and m.to_q.bias is None and m.to_k.bias is None and m.to_v.bias is None:
+                        if x.is_cuda and ops.self_attn_supported(x.shape[-1], m.heads):
+                            return to_out(ops.self_attention_block(x, m.to_q.weight, m.to_k.weight, m.to_v.weight, m.heads,
+                                                                   m.scale))
+                        q, k, v = ops.qkv_proj(x, m.to_q.weight, m.to_k.weight, m.to_v.weight)
+                        return to_out(_attention_core(m, q, k, v, False))
                     return to_out(_attention_core(m, m.to_q(x), m.to_k(ctx), m.to_v(ctx), is_cross))
                 return forward
             mod.forward = make(mod)

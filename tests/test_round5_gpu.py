@@ -276,3 +276,67 @@ def test_split_bf16_flash_attention_backward_vs_fp64(B, H, N):
     finally:
         ops.FLASH_SPLIT, ops.FLASH_SPLIT_MIN_KEYS = prev, pmin
     assert torch.equal(qa.grad, dq) and torch.equal(ka.grad, dk) and torch.equal(va.grad, dv)
+
+
+@pytest.mark.parametrize("B,H,N,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (3, 8, 256, 160), (1, 8, 64, 160), (1, 3, 300, 40)])
+def test_self_attention_block_stacked_projections_vs_fp64(B, H, N, d):
+    """q | k | v as one batched GEMM + the flash backward writing dq | dk | dv as column bands of one [B*N, 3C] buffer
+    (skp_flash_attn_bwd_ld_f32) + ONE input-gradient GEMM: output and dx against an fp64 reference of the block
+    (ptp_utils.py:513-520, 493-506) and against the three-projection composition it replaces."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C = H * d
+    x64 = torch.randn(B, N, C, generator=g, dtype=torch.float64)
+    w64 = [torch.randn(C, C, generator=g, dtype=torch.float64) * C ** -0.5 for _ in range(3)]
+    go64 = torch.randn(B, N, C, generator=g, dtype=torch.float64)
+    scale = d ** -0.5
+
+    def ref(x, ws):
+        q, k, v = (torch.nn.functional.linear(x, w) for w in ws)
+        sp = lambda t: t.reshape(B, N, H, d).permute(0, 2, 1, 3)
+        p = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * scale, dim=-1)
+        return (p @ sp(v)).permute(0, 2, 1, 3).reshape(B, N, C)
+
+    xr = x64.clone().requires_grad_(True)
+    o64 = ref(xr, w64)
+    (dx64,) = torch.autograd.grad(o64, xr, go64)
+    x = x64.float().cuda().requires_grad_(True)
+    ws = [w.float().cuda() for w in w64]
+    go = go64.float().cuda()
+    out = ops.self_attention_block(x, *ws, H, scale)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("SelfAttnQKVFn")
+    (dx,) = torch.autograd.grad(out, x, go)
+    x2 = x.detach().clone().requires_grad_(True)
+    q, k, v = (torch.nn.functional.linear(x2, w) for w in ws)
+    out2 = ops.self_attention(q, k, v, H, scale)
+    (dx2,) = torch.autograd.grad(out2, x2, go)
+    eo, eo2 = (out.double().cpu() - o64).abs().max().item(), (out2.double().cpu() - o64).abs().max().item()
+    ed, ed2 = (dx.double().cpu() - dx64).abs().max().item(), (dx2.double().cpu() - dx64).abs().max().item()
+    so, sd = o64.abs().max().item(), dx64.abs().max().item()
+    print(f"B={B} H={H} N={N} d={d}: out {eo / so:.2e} (three GEMMs {eo2 / so:.2e})  dx {ed / sd:.2e} (three GEMMs {ed2 / sd:.2e})")
+    assert eo <= 2.0 * eo2 + 1e-6 * so and ed <= 2.0 * ed2 + 1e-6 * sd
+    assert eo < 2e-5 * so and ed < 2e-5 * sd
+    # the strided entry against the dense one, bit for bit (same kernels, different row stride)
+    qd, kd, vd = (t.detach().contiguous() for t in (q, k, v))
+    o, lse = out2.detach(), None
+    fa = ops.FlashAttnFn
+    ctx_out = torch.empty_like(qd)
+    lse = torch.empty(B, H, N, device="cuda")
+    ops.N.check(ops.N.lib().skp_flash_attn_fwd_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ctx_out.data_ptr(), lse.data_ptr(),
+                                                   B, B, H, N, N, d, float(scale), ops._stream()), "fwd")
+    nb = ops.N.lib().skp_flash_attn_bwd_workspace(B, B, H, N, N, d)
+    wsb = torch.empty(nb // 4, device="cuda")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(qd), torch.empty_like(qd)
+    ops.N.check(ops.N.lib().skp_flash_attn_bwd_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ctx_out.data_ptr(), go.data_ptr(),
+                                                   lse.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), wsb.data_ptr(),
+                                                   B, B, H, N, N, d, float(scale), ops._stream()), "bwd")
+    d3 = torch.full((B * N, 3 * C + 8), float("nan"), device="cuda")
+    p = d3.data_ptr()
+    ops.N.check(ops.N.lib().skp_flash_attn_bwd_ld_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ctx_out.data_ptr(), go.data_ptr(),
+                                                      lse.data_ptr(), p, p + 4 * C, p + 8 * C, wsb.data_ptr(), B, B, H, N, N, d,
+                                                      float(scale), 3 * C + 8, ops._stream()), "bwd_ld")
+    assert torch.equal(d3[:, :C], dq.view(-1, C)) and torch.equal(d3[:, C:2 * C], dk.view(-1, C)) and torch.equal(d3[:, 2 * C:3 * C], dv.view(-1, C))
+    assert torch.isnan(d3[:, 3 * C:]).all()                      # nothing written outside the three bands
+    assert ops.N.lib().skp_flash_attn_bwd_ld_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ctx_out.data_ptr(), go.data_ptr(),
+                                                 lse.data_ptr(), p, p, p, wsb.data_ptr(), B, B, H, N, N, d, float(scale), C - 4,
+                                                 ops._stream()) != 0
