@@ -1273,6 +1273,20 @@ def _qkv_stack(wq, wk, wv):
     return w3
 
 
+def weight_stack(ws):
+    """[len(ws), N, K] stack of frozen [N, K] weights, made once per list of parameters (their identities / versions are
+    checked on every use, like the other derived buffers of frozen weights)."""
+    import weakref
+    key = tuple(w.data_ptr() for w in ws) + (tuple(ws[0].shape), ws[0].device)
+    ver = tuple(w._version for w in ws)
+    hit = _QKV_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is ws[0]:
+        return hit[1]
+    w3 = torch.stack([w.detach() for w in ws]).contiguous()
+    _QKV_CACHE[key] = (ver, w3, weakref.ref(ws[0]))
+    return w3
+
+
 QKV_STACKED = os.environ.get("SKP_QKV_STACKED", "1") != "0"   # A/B switch: one batched GEMM with a broadcast A operand
 
 

@@ -17,9 +17,11 @@ What changes under the hood
 from __future__ import annotations
 
 import abc
+import os
 from typing import Optional
 
 import numpy as np
+
 import torch
 
 from . import ops
@@ -86,6 +88,59 @@ MAX_STORED_LAYERS = 4          # ptp_utils.py:511
 MAX_STORED_SEQ = 32 ** 2       # ptp_utils.py:510
 
 
+# ---------------------------------------------------------------------------------------------
+# context projections of one forward                          reference ptp_utils.py:513-520
+# ---------------------------------------------------------------------------------------------
+CTX_KV_BATCHED = os.environ.get("SKP_CTX_KV", "1") != "0"       # A/B switch
+_CTX_KV = {}                 # id(CrossAttention module) -> (k, v) [1,T,C] of the forward in flight
+
+
+def _context_kv_begin(unet, context):
+    """k = to_k(context), v = to_v(context) of the cross-attention layers for the ONE shared context row, before the UNet
+    runs: the reference expands the learned embedding to the batch and projects it inside every layer (B x 77 rows through
+    2 x 16 small GEMMs, as many again backward plus their accumulation adds).  The rows are identical, the weights frozen
+    and bias-free: one batched GEMM per layer width (stacked weights, broadcast A operand) gives every layer its [1,T,C]
+    pair, the attention kernels take a shared k / v (Bk = 1) and autograd sums the layers' gradients in one stack + one
+    batched GEMM per width.  Layers that did not consume their pair in an earlier forward (beyond the early exit) are left
+    out from the second forward on; a layer without a pair projects for itself, as before."""
+    _CTX_KV.clear()
+    if not (CTX_KV_BATCHED and context.is_cuda and context.dim() == 3 and context.shape[0] == 1):
+        return
+    plan = getattr(unet, "_skp_ctx_plan", None)
+    if plan is None:
+        mods = [m.attn2 for m in unet.modules() if m.__class__.__name__ == "BasicTransformerBlock" and hasattr(m, "attn2")]
+        mods = [m for m in mods if m.to_k.bias is None and m.to_v.bias is None and not m.to_k.weight.requires_grad
+                and not m.to_v.weight.requires_grad and m.to_k.weight.shape[1] == context.shape[-1]
+                and "forward" not in m.to_k.__dict__ and "forward" not in m.to_v.__dict__]
+        plan = {"mods": mods, "used": None}
+        unet._skp_ctx_plan = plan
+    mods = plan["mods"] if plan["used"] is None else [m for m in plan["mods"] if id(m) in plan["used"]]
+    if plan["used"] is None:
+        plan["used"] = set()
+    groups = {}
+    for m in mods:
+        groups.setdefault(m.to_k.weight.shape[0], []).append(m)
+    ctx2 = context[0]
+    for c, ms in groups.items():
+        w = ops.weight_stack([t for m in ms for t in (m.to_k.weight, m.to_v.weight)])        # [2n, C, Dctx], made once
+        kv = torch.bmm(ctx2.unsqueeze(0).expand(w.shape[0], -1, -1), w.transpose(1, 2)).unbind(0)
+        for i, m in enumerate(ms):
+            _CTX_KV[id(m)] = (kv[2 * i].unsqueeze(0), kv[2 * i + 1].unsqueeze(0), unet._skp_ctx_plan["used"])
+
+
+def _context_kv_end():
+    _CTX_KV.clear()
+
+
+def _context_kv(module):
+    """(k, v) of `module` for the forward in flight, or None (no shared-context forward, or the layer was left out)."""
+    hit = _CTX_KV.get(id(module))
+    if hit is None:
+        return None
+    hit[2].add(id(module))
+    return hit[0], hit[1]
+
+
 def _attention_core(module, q, k, v, is_cross=False):
     """softmax(scale q k^T) v per head (ptp_utils.py:493-506) on [B,N,C]/[B,T,C] tensors.  Cross layers with
     a short key axis run on the fused fp32-MFMA kernel (csrc/skp_cross_attn.hip); self-attention runs on the
@@ -127,7 +182,9 @@ def register_attention_control(model, controller, feature_upsample_res=256):
                     and len(controller.step_store["attn"]) < MAX_STORED_LAYERS):
                 # early exit: this is the LAST map the gate will store and the forward ends here (the caller discards the
                 # prediction, ptp_utils.py:246) -- the layer's value projection and attention output have no consumer
-                rec = FusedAttn(self.to_q(x), self.to_k(ctx), self.heads, self.scale, feature_upsample_res)
+                pre = _context_kv(self)
+                rec = FusedAttn(self.to_q(x), pre[0] if pre is not None else self.to_k(ctx), self.heads, self.scale,
+                                feature_upsample_res)
                 if getattr(controller, "materialize", False):
                     rec = rec.materialize()
                 controller({"attn": rec}, is_cross, place_in_unet)
@@ -140,8 +197,8 @@ def register_attention_control(model, controller, feature_upsample_res=256):
                 q, k, v = ops.qkv_proj(x, self.to_q.weight, self.to_k.weight, self.to_v.weight)
             else:
                 q = self.to_q(x)
-                k = self.to_k(ctx)
-                v = self.to_v(ctx)
+                pre = _context_kv(self) if is_cross else None
+                k, v = pre if pre is not None else (self.to_k(ctx), self.to_v(ctx))
             out = _attention_core(self, q, k, v, is_cross)
             if (is_cross and sequence_length <= MAX_STORED_SEQ
                     and len(controller.step_store["attn"]) < MAX_STORED_LAYERS):
@@ -207,7 +264,9 @@ def accelerate_cross_attention(net):
                                                                    m.scale))
                         q, k, v = ops.qkv_proj(x, m.to_q.weight, m.to_k.weight, m.to_v.weight)
                         return to_out(_attention_core(m, q, k, v, False))
-                    return to_out(_attention_core(m, m.to_q(x), m.to_k(ctx), m.to_v(ctx), is_cross))
+                    pre = _context_kv(m) if is_cross else None
+                    k, v = pre if pre is not None else (m.to_k(ctx), m.to_v(ctx))
+                    return to_out(_attention_core(m, m.to_q(x), k, v, is_cross))
                 return forward
             mod.forward = make(mod)
 
@@ -248,10 +307,12 @@ def find_pred_noise(ldm, image, context, noise_level=-1, device="cuda", noise=No
         for c in controllers.values():
             c.stop_after = MAX_STORED_LAYERS
     try:
+        _context_kv_begin(ldm.unet, context)
         pred_noise = ldm.unet(noisy_image, t.repeat(b), context.expand(b, -1, -1) if context.shape[0] == 1 else context)["sample"]
     except StopForward:
         pred_noise = None
     finally:
+        _context_kv_end()
         if early_exit and controllers is not None:
             for c in controllers.values():
                 c.stop_after = None

@@ -340,3 +340,32 @@ def test_self_attention_block_stacked_projections_vs_fp64(B, H, N, d):
     assert ops.N.lib().skp_flash_attn_bwd_ld_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ctx_out.data_ptr(), go.data_ptr(),
                                                  lse.data_ptr(), p, p, p, wsb.data_ptr(), B, B, H, N, N, d, float(scale), C - 4,
                                                  ops._stream()) != 0
+
+
+def test_batched_context_projections_equal_per_layer_projections(monkeypatch):
+    """k / v of every cross-attention layer from the ONE shared context row (one batched GEMM per layer width, Bk = 1 through
+    the attention and map kernels) against the per-layer projections of the expanded context (ptp_utils.py:513-520): same
+    loss, same embedding gradient; layers beyond the early exit are left out from the second forward on."""
+    from test_e2e_gpu import _setup
+    from oracle import ref_path as R
+    from stablekeypoints_amd import ptp_utils
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import group_step
+    ldm, controllers, cpu, images, ctx, noise, args = _setup()
+    n = images.shape[0]
+    dev, controller = next(iter(controllers.items()))
+    thetas = torch.cat([R.affine_matrix(11.0, 0.87, (0.13, -0.21)), R.affine_matrix(-9.0, 0.93, (-0.2, 0.1))])
+    tr = RandomAffineWithInverse()
+    out = {}
+    for mode in (False, True, True):
+        monkeypatch.setattr(ptp_utils, "CTX_KV_BATCHED", mode)
+        c = ctx.clone().cuda().requires_grad_(True)
+        loss, eq, sh = group_step(ldm, images, c, args, controller, tr, denom=n, noise=noise.cuda(), thetas=thetas)
+        out.setdefault(mode, []).append((loss.item(), eq.item(), sh.item(), c.grad.clone()))
+    plan = ldm.unet._skp_ctx_plan
+    assert 0 < len(plan["used"]) < len(plan["mods"])               # the early exit leaves the last up-block layers out
+    ref = out[False][0]
+    for got in out[True]:                                          # first forward (all layers projected) and second (used ones only)
+        assert abs(got[0] - ref[0]) <= 1e-5 * abs(ref[0]) and abs(got[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-9
+        torch.testing.assert_close(got[3], ref[3], rtol=1e-4, atol=1e-5 * ref[3].abs().max().item())
+    assert not ptp_utils._CTX_KV                                   # nothing of a finished forward stays behind
