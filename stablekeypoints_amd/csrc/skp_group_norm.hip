@@ -10,6 +10,7 @@
 //   bwd    : dz = dy * act'(z);  dx = rstd * (g - mean_grp(g) - xhat * mean_grp(g * xhat)),  g = dz * gamma[c]
 // HBM-bound: 1 read for stats + 1 read + 1 write for apply (3 passes instead of 5+).
 #include "skp_common.h"
+#include <stdlib.h>
 
 struct GNArgs {
     const float* x; const float* off; const float* gamma; const float* beta;
@@ -221,6 +222,165 @@ __global__ __launch_bounds__(256) void skp_gn_bwd_apply_kernel(GNArgs a, const f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-pass forms for rows that fit the registers of one workgroup (every GroupNorm of the UNet: (C/G) * HW <= 64 K elements).
+// The multi-kernel forms above cost a UNet GroupNorm 2-3 launches of ~8-12 us each on a few hundred KB (statistics or block
+// merge, [coefficients,] apply) and two more backward -- launch ramp and tail, not bandwidth.  Here ONE workgroup of 1024
+// threads owns a (sample, group) row: the row is read once into registers (VPT float4 per thread), mean and variance are two
+// in-register passes (exact two-pass form, no shifted sums needed), the normalised (+SiLU) row is written from the registers;
+// backward: x and dy in registers, the two group sums, dx.  Fixed-order reductions (wave butterflies, then the 16 waves): the
+// result is bit-reproducible.  HBM traffic: 1 read + 1 write forward (was 2 + 1), 2 reads + 1 write backward (was 4 + 1).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float skp_block_sum_1024(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();                                           // `red` may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+}
+
+template <int VPT>
+__global__ __launch_bounds__(1024) void skp_gn_onepass_fwd_kernel(GNArgs a, float* __restrict__ y, float* __restrict__ mean_out,
+                                                                  float* __restrict__ rstd_out) {
+    __shared__ float red[16];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
+    const float* xr = a.x + (size_t)row * a.L;
+    float* yr = y + (size_t)row * a.L;
+    const int hw4 = a.HW / 4, q4 = (int)(a.L / 4);
+    f32x4 v[VPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = tid + 1024 * j;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < q4) {
+            v[j] = *(const f32x4*)(xr + (size_t)i * 4);
+            if (a.off) v[j] += a.off[(size_t)n * a.C + g * Cg + i / hw4];
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    const float mean = skp_block_sum_1024(s, red) / (float)a.L;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+        if (tid + 1024 * j < q4) {
+            const f32x4 d = v[j] - mean;
+            s2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    const float var = skp_block_sum_1024(s2, red) / (float)a.L;
+    const float rstd = 1.0f / sqrtf(var + a.eps);
+    if (tid == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = tid + 1024 * j;
+        if (i < q4) {
+            const int c = g * Cg + i / hw4;
+            const float sc = rstd * a.gamma[c];
+            const float sh = a.beta[c] - mean * sc;             // the offset is already inside v
+            f32x4 r = v[j] * sc + sh;
+            if (a.silu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = r[e] / (1.0f + __expf(-r[e]));
+            }
+            *(f32x4*)(yr + (size_t)i * 4) = r;
+        }
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(1024) void skp_gn_onepass_bwd_kernel(GNArgs a, const float* __restrict__ dy, const float* __restrict__ mean_in,
+                                                                  const float* __restrict__ rstd_in, float* __restrict__ dx) {
+    __shared__ float red[16];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float* xr = a.x + (size_t)row * a.L;
+    const float* dr = dy + (size_t)row * a.L;
+    float* dxr = dx + (size_t)row * a.L;
+    const int hw4 = a.HW / 4, q4 = (int)(a.L / 4);
+    f32x4 xh[VPT], gz[VPT];                                    // xhat and g = dy * act'(z) * gamma of this thread's elements
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = tid + 1024 * j;
+        xh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gz[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < q4) {
+            const int c = g * Cg + i / hw4;
+            const float gam = a.gamma[c], bet = a.beta[c];
+            const float o = a.off ? a.off[(size_t)n * a.C + c] : 0.f;
+            const f32x4 xv = *(const f32x4*)(xr + (size_t)i * 4);
+            const f32x4 dv = *(const f32x4*)(dr + (size_t)i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (xv[e] + o - mean) * rstd;
+                float t = dv[e];
+                if (a.silu) {
+                    const float z = h * gam + bet;
+                    const float sg = 1.0f / (1.0f + __expf(-z));
+                    t *= sg * (1.0f + z * (1.0f - sg));
+                }
+                t *= gam;
+                xh[j][e] = h; gz[j][e] = t;
+                s1 += t; s2 += t * h;
+            }
+        }
+    }
+    const float m1 = skp_block_sum_1024(s1, red) / (float)a.L;
+    const float m2 = skp_block_sum_1024(s2, red) / (float)a.L;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = tid + 1024 * j;
+        if (i < q4) *(f32x4*)(dxr + (size_t)i * 4) = (gz[j] - m1 - xh[j] * m2) * rstd;
+    }
+}
+
+// float4 per thread the one-pass forms would need for this row length; 0 = not served (SKP_GN_ONEPASS=0 switches them off)
+static int gn_onepass_vpt(const GNArgs& a, bool backward) {
+    static const bool on = [] { const char* e = getenv("SKP_GN_ONEPASS"); return !(e && e[0] == '0'); }();
+    if (!on) return 0;
+    const long q4 = a.L / 4, need = (q4 + 1023) / 1024;
+    // (the forward at 8 float4 per thread is left out: this compiler spills it -- 128 registers + 408 bytes of scratch -- while
+    // 10 and 16 compile clean at 86 / 122; the backward holds two arrays and stops at 10 = 112 registers)
+    const int fsizes[] = {1, 2, 4, 10, 16}, bsizes[] = {1, 2, 4, 8, 10};
+    for (int k = 0; k < 5; ++k) {
+        const int v = backward ? bsizes[k] : fsizes[k];
+        if (need <= v) return v;
+    }
+    return 0;
+}
+
+static int gn_onepass_fwd(const GNArgs& a, float* y, float* mean, float* rstd, hipStream_t st) {
+    const dim3 grid(a.N * a.G), block(1024);
+    switch (gn_onepass_vpt(a, false)) {
+        case 1: hipLaunchKernelGGL(skp_gn_onepass_fwd_kernel<1>, grid, block, 0, st, a, y, mean, rstd); break;
+        case 2: hipLaunchKernelGGL(skp_gn_onepass_fwd_kernel<2>, grid, block, 0, st, a, y, mean, rstd); break;
+        case 4: hipLaunchKernelGGL(skp_gn_onepass_fwd_kernel<4>, grid, block, 0, st, a, y, mean, rstd); break;
+        case 10: hipLaunchKernelGGL(skp_gn_onepass_fwd_kernel<10>, grid, block, 0, st, a, y, mean, rstd); break;
+        case 16: hipLaunchKernelGGL(skp_gn_onepass_fwd_kernel<16>, grid, block, 0, st, a, y, mean, rstd); break;
+        default: return -100;
+    }
+    return skp_launch_status();
+}
+
+static int gn_onepass_bwd(const GNArgs& a, const float* dy, const float* mean, const float* rstd, float* dx, hipStream_t st) {
+    const dim3 grid(a.N * a.G), block(1024);
+    switch (gn_onepass_vpt(a, true)) {
+        case 1: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<1>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
+        case 2: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<2>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
+        case 4: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<4>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
+        case 8: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<8>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
+        case 10: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<10>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
+        default: return -100;
+    }
+    return skp_launch_status();
+}
+
 static int gn_fill(GNArgs& a, const float* x, const float* off, const float* gamma, const float* beta, int N, int C,
                    int G, int HW, float eps, int silu) {
     if (!x || !gamma || !beta || N <= 0 || C <= 0 || G <= 0 || HW <= 0) return SKP_E_BADARG;
@@ -252,6 +412,7 @@ extern "C" int skp_group_norm_fwd_f32(const float* x, const float* off, const fl
     if (rc) return rc;
     if (!y || !mean || !rstd || !workspace) return SKP_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (gn_onepass_vpt(a, false)) return gn_onepass_fwd(a, y, mean, rstd, st);
     hipLaunchKernelGGL(skp_gn_stats_kernel, dim3(a.nsplit, N * G), dim3(256), 0, st, a, workspace);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -274,6 +435,7 @@ extern "C" int skp_group_norm_fwd_blocks_f32(const float* x, const float* off, c
     if (!y || !mean || !rstd || !bs || nblk <= 0 || pix <= 0) return SKP_E_BADARG;
     if ((long)nblk * pix != HW) return SKP_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
+    if (gn_onepass_vpt(a, false)) return gn_onepass_fwd(a, y, mean, rstd, st);   // the row is in registers anyway: exact statistics
     hipLaunchKernelGGL(skp_gn_from_blocks_kernel, dim3(N * G), dim3(256), 0, st, a, bs, nblk, pix, mean, rstd);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -338,6 +500,7 @@ extern "C" int skp_group_norm_bwd_f32(const float* x, const float* off, const fl
     if (rc) return rc;
     if (!dy || !mean || !rstd || !dx || !workspace) return SKP_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (gn_onepass_vpt(a, true)) return gn_onepass_bwd(a, dy, mean, rstd, dx, st);
     hipLaunchKernelGGL(skp_gn_bwd_stats_kernel, dim3(a.nsplit, N * G), dim3(256), 0, st, a, dy, mean, rstd, workspace);
     rc = skp_launch_status();
     if (rc) return rc;

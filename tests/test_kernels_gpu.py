@@ -312,7 +312,11 @@ def test_other_baseline_config_shapes_vs_fp64(ops, name, layers, heads, T, Rr):
 
 @pytest.mark.parametrize("N,C,G,H,W,silu,with_off", [(2, 64, 32, 16, 16, True, True), (8, 320, 32, 64, 64, True, True),
                                                       (1, 128, 32, 40, 24, False, False), (3, 32, 32, 6, 6, True, False),
-                                                      (2, 512, 32, 128, 128, True, False)])
+                                                      (2, 512, 32, 128, 128, True, False),
+                                                      # one-pass forms (row in registers): 2 / 4 / 8-10 / 16 float4 per thread; the
+                                                      # last one's backward (61 440 elements per row) takes the two-kernel form
+                                                      (2, 2560, 32, 8, 8, False, True), (2, 1280, 32, 16, 16, True, False),
+                                                      (2, 640, 32, 32, 32, True, True), (2, 1920, 32, 32, 32, True, True)])
 def test_fused_group_norm_silu_fwd_bwd(ops, N, C, G, H, W, silu, with_off):
     g = torch.Generator().manual_seed(4)
     x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.7)

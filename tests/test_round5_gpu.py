@@ -369,3 +369,33 @@ def test_batched_context_projections_equal_per_layer_projections(monkeypatch):
         assert abs(got[0] - ref[0]) <= 1e-5 * abs(ref[0]) and abs(got[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-9
         torch.testing.assert_close(got[3], ref[3], rtol=1e-4, atol=1e-5 * ref[3].abs().max().item())
     assert not ptp_utils._CTX_KV                                   # nothing of a finished forward stays behind
+
+
+@pytest.mark.parametrize("N,C,H,W", [(8, 1280, 16, 16), (2, 320, 64, 64), (8, 640, 32, 32)])
+def test_one_pass_group_norm_statistics_far_from_zero(N, C, H, W):
+    """One-pass GroupNorm (row in registers, two in-register passes for mean and variance) on rows whose mean dwarfs their spread
+    (mean 50, spread 0.1: a one-sweep sum / sum-of-squares form loses every digit of the variance here), forward and backward
+    against fp64; repeat runs bit-identical."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, W, generator=g) * 0.1 + 50.0
+    w = torch.randn(N, C, H, W, generator=g)
+    norm = torch.nn.GroupNorm(32, C, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g)); norm.bias.copy_(torch.randn(C, generator=g))
+    xd = x.double().requires_grad_(True)
+    nd = torch.nn.GroupNorm(32, C, eps=1e-5).double()
+    nd.load_state_dict({k: v.double() for k, v in norm.state_dict().items()})
+    ref = torch.nn.functional.silu(nd(xd))
+    (ref * w.double()).sum().backward()
+    norm = norm.cuda()
+    outs = []
+    for _ in range(2):
+        xg = x.cuda().requires_grad_(True)
+        y = ops.group_norm_silu(xg, norm)
+        (y * w.cuda()).sum().backward()
+        outs.append((y.detach().clone(), xg.grad.clone()))
+    # the input itself is only known to 50 * 2^-24 = 3e-6 against a spread of 0.1: 3e-5 relative in xhat
+    torch.testing.assert_close(outs[0][0].cpu().double(), ref.detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(outs[0][1].cpu().double(), xd.grad, rtol=1e-3, atol=2e-4 * xd.grad.abs().max().item())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
