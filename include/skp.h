@@ -349,6 +349,12 @@ int skp_group_norm_fwd_blocks_f32(const float* x, const float* off, const float*
 int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int Cin, void* stream);
 int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
                        int pad, void* stream);
+/* The same with scratch for a K split over the input channels where the launch alone would not fill the chip (the UNet's
+ * down-sampling layers at a few rows: 80-192 workgroups): skp_conv3x3_s2_workspace() bytes (0 = none needed, pass NULL);
+ * partial sums per split, added in fixed order with the bias by a second kernel.  Deterministic. */
+int64_t skp_conv3x3_s2_workspace(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_s2_ws_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin, int Cout,
+                          int H, int W, int pad, void* stream);
 
 /* 3x3 / stride 1 / padding 1 convolution with AT MOST FOUR input channels (the `conv_in` layers: VAE encoder 3 -> 128 on the
  * image, ptp_utils.py:289-304; UNet 4 -> 320 on the latents, ptp_utils.py:227), forward, NCHW, bias folded in (may be NULL).

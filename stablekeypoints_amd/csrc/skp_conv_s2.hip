@@ -18,6 +18,7 @@
 // (position fixed per thread, channel = scalar offset: no address arithmetic in the loop; out-of-range offsets return 0 =
 // the zero padding) while the current stage computes, and goes to the other LDS buffer afterwards (one barrier per stage).
 #include "skp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,6 +44,11 @@ struct S2Args {
     int tilesX, tilesPerImg;
     unsigned x_bytes, u_bytes, y_bytes;
     float* stats;            // optional [B][Cout][tilesPerImg][2] = {mean, sum (y - mean)^2} per 8x16-pixel tile (next GroupNorm), or null
+    // K split (small grids: the UNet's down-sampling layers are 80-192 workgroups at 8 rows): blockIdx.z = split, each takes
+    // `per` 16-channel stages and writes its partial sums (no bias) to part + z * y_elems; skp_conv_s2_reduce_kernel adds them
+    int nsplit, per;
+    float* part;
+    unsigned y_elems;
 };
 
 __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
@@ -54,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
     const int oy0 = ty * S2_TOH, ox0 = tx * S2_TOW;
     const int HW = a.H * a.W;
     const int co0 = cg * 128 + wave * 32;
-    const int nsteps = a.Cin >> 4, C16 = nsteps;
+    const int C16 = a.Cin >> 4;
+    const int s_begin = a.nsplit > 1 ? (int)blockIdx.z * a.per : 0;
+    const int s_end = a.nsplit > 1 ? min(C16, s_begin + a.per) : C16;
 
     // ---- staging role: thread -> up to 3 fixed positions of the 17 x 33 patch; the channel is a scalar offset ----
     int goff[S2_SLOTS], loff[S2_SLOTS];
@@ -99,13 +107,13 @@ __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
     for (int mt = 0; mt < 2; ++mt) uvo[mt] = (kq * a.Cout + min(co0 + 16 * mt + i16, a.Cout - 1)) * 16;
     const int u_c16 = 4 * a.Cout * 16, u_tap = C16 * u_c16;
 
-    fetch(0);
+    fetch(s_begin);
     put(0);
     __syncthreads();
 
-    for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) fetch(s + 1);
-        const float* xb = xs + (s & 1) * S2_STAGE + kq * (S2_POS * 4);
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) fetch(s + 1);
+        const float* xb = xs + ((s - s_begin) & 1) * S2_STAGE + kq * (S2_POS * 4);
         f32x4 ua[3][2];                                           // filter ring, two taps ahead
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -129,13 +137,14 @@ __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
                     for (int mt = 0; mt < 2; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[tap % 3][mt][m], bv[nt][m], acc[mt][nt], 0, 0, 0);
         }
-        if (s + 1 < nsteps) put((s + 1) & 1);
+        if (s + 1 < s_end) put((s + 1 - s_begin) & 1);
         __syncthreads();
     }
 
     // ---- epilogue: lane = pixel (16 consecutive ox of row oy0 + nt), registers = 4 output channels ----
-    const i32x4 yrs = skp_make_rsrc(a.y, a.y_bytes);
-    const i32x4 brs = skp_make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+    const bool split = a.nsplit > 1;
+    const i32x4 yrs = skp_make_rsrc(split ? a.part + (size_t)blockIdx.z * a.y_elems : a.y, a.y_bytes);
+    const i32x4 brs = skp_make_rsrc(a.bias, (a.bias && !split) ? (unsigned)a.Cout * 4u : 0u);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -175,6 +184,31 @@ __global__ __launch_bounds__(256, 2) void skp_conv_s2_kernel(S2Args a) {
         }
 }
 
+// y = bias[c] + sum over the splits of part[z]   (fixed order; float4 per thread, OH * OW % 4 == 0)
+__global__ __launch_bounds__(256) void skp_conv_s2_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, unsigned n4, unsigned stride, int nsplit,
+                                                                 int hw4, int Cout) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = ((const f32x4*)part)[i];
+    for (int z = 1; z < nsplit; ++z) acc += ((const f32x4*)(part + (size_t)z * stride))[i];
+    if (bias) acc += bias[(i / hw4) % Cout];
+    ((f32x4*)y)[i] = acc;
+}
+
+// K splits of a launch: enough workgroups for two per CU, at least four 16-channel stages each, at most eight
+static int s2_splits(int B, int Cin, int Cout, int H, int W) {
+    static const bool on = [] { const char* e = getenv("SKP_S2_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!on) return 1;
+    const long wgs = (long)B * ((H / 2) / S2_TOH) * ((W / 2) / S2_TOW) * ((Cout + 127) / 128);
+    if (wgs >= 256) return 1;
+    long s = (512 + wgs - 1) / wgs;
+    const long cap = (Cin >> 4) / 4;
+    if (s > cap) s = cap;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : (int)s;
+}
+
 }  // namespace
 
 extern "C" int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int Cin, void* stream) {
@@ -186,23 +220,38 @@ extern "C" int skp_conv3x3_s2_filter_f32(const void* w, void* U, int Cout, int C
     return skp_launch_status();
 }
 
-static int s2_run(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin, int Cout, int H, int W,
-                  int pad, void* stream);
+static int s2_run(const void* x, const void* U, const void* bias, void* y, float* stats, float* workspace, int B, int Cin, int Cout,
+                  int H, int W, int pad, void* stream);
 
 extern "C" int skp_conv3x3_s2_f32(const void* x, const void* U, const void* bias, void* y, int B, int Cin, int Cout, int H,
                                   int W, int pad, void* stream) {
-    return s2_run(x, U, bias, y, nullptr, B, Cin, Cout, H, W, pad, stream);
+    return s2_run(x, U, bias, y, nullptr, nullptr, B, Cin, Cout, H, W, pad, stream);
+}
+
+// Bytes of scratch skp_conv3x3_s2_ws_f32 wants for this shape: 0 = the launch fills the chip on its own; else the partial sums
+// of a K split (small grids: 640 -> 640 @32^2, 8 rows is 80 workgroups of 128 channels x 128 pixels on 256 CUs).
+extern "C" int64_t skp_conv3x3_s2_workspace(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (Cin & 15) || (H & 1) || (W & 1)) return 0;
+    if (((H / 2) % S2_TOH) || ((W / 2) % S2_TOW)) return 0;
+    const int s = s2_splits(B, Cin, Cout, H, W);
+    return s > 1 ? (int64_t)s * B * Cout * (H / 2) * (W / 2) * 4 : 0;
+}
+
+// skp_conv3x3_s2_f32 with that scratch (NULL where skp_conv3x3_s2_workspace is 0): same result up to the summation order
+extern "C" int skp_conv3x3_s2_ws_f32(const void* x, const void* U, const void* bias, void* y, void* workspace, int B, int Cin,
+                                     int Cout, int H, int W, int pad, void* stream) {
+    return s2_run(x, U, bias, y, nullptr, (float*)workspace, B, Cin, Cout, H, W, pad, stream);
 }
 
 // as above + stats [B][Cout][(H/16)*(W/32)][2]: {mean, sum of squared deviations} of y over each 8x16-pixel output tile
 extern "C" int skp_conv3x3_s2_stats_f32(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin,
                                         int Cout, int H, int W, int pad, void* stream) {
     if (!stats) return SKP_E_BADARG;
-    return s2_run(x, U, bias, y, stats, B, Cin, Cout, H, W, pad, stream);
+    return s2_run(x, U, bias, y, stats, nullptr, B, Cin, Cout, H, W, pad, stream);
 }
 
-static int s2_run(const void* x, const void* U, const void* bias, void* y, float* stats, int B, int Cin, int Cout, int H, int W,
-                  int pad, void* stream) {
+static int s2_run(const void* x, const void* U, const void* bias, void* y, float* stats, float* workspace, int B, int Cin, int Cout,
+                  int H, int W, int pad, void* stream) {
     if (!x || !U || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (pad != 0 && pad != 1)) return SKP_E_BADARG;
     if ((Cin & 15) || (Cout & 31) || (H & 1) || (W & 1)) return SKP_E_RANGE;
     const int OH = H / 2, OW = W / 2;
@@ -217,6 +266,10 @@ static int s2_run(const void* x, const void* U, const void* bias, void* y, float
     a.tilesPerImg = a.tilesX * (OH / S2_TOH);
     a.x_bytes = (unsigned)xb; a.u_bytes = (unsigned)ub; a.y_bytes = (unsigned)yb;
     a.stats = stats;
+    a.nsplit = (workspace && !stats) ? s2_splits(B, Cin, Cout, H, W) : 1;
+    a.per = ((Cin >> 4) + a.nsplit - 1) / a.nsplit;
+    a.part = workspace;
+    a.y_elems = (unsigned)(yb / 4);
     const long tiles = (long)B * a.tilesPerImg;
     if (tiles > 0x7fffffffL) return SKP_E_RANGE;
     const size_t lds = (size_t)2 * S2_STAGE * sizeof(float);
@@ -226,6 +279,11 @@ static int s2_run(const void* x, const void* U, const void* bias, void* y, float
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(skp_conv_s2_kernel, dim3((unsigned)tiles, (Cout + 127) / 128), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(skp_conv_s2_kernel, dim3((unsigned)tiles, (Cout + 127) / 128, a.nsplit), dim3(256), lds, (hipStream_t)stream, a);
+    int rc = skp_launch_status();
+    if (rc || a.nsplit == 1) return rc;
+    const unsigned n4 = a.y_elems / 4;
+    hipLaunchKernelGGL(skp_conv_s2_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                       (const float*)bias, (float*)y, n4, a.y_elems, a.nsplit, OH * OW / 4, Cout);
     return skp_launch_status();
 }

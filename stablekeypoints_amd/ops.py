@@ -1482,8 +1482,11 @@ def _conv3x3_s2_raw(x, weight, bias, pad, want_stats):
                 "skp_conv3x3_s2_stats_f32")
         y._skp_blocks = (stats, nblk, 128)
         return y
-    N.check(N.lib().skp_conv3x3_s2_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                       B, ci, co, H, W, int(pad), _stream()), "skp_conv3x3_s2_f32")
+    nbytes = N.lib().skp_conv3x3_s2_workspace(B, ci, co, H, W)    # > 0: small grid, K split over the input channels
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes > 0 else None
+    N.check(N.lib().skp_conv3x3_s2_ws_f32(x.data_ptr(), U.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                          ws.data_ptr() if ws is not None else None, B, ci, co, H, W, int(pad), _stream()),
+            "skp_conv3x3_s2_ws_f32")
     return y
 
 

@@ -410,7 +410,9 @@ def test_sd21_sdxl_full_width_trees_one_forward(ops):
 
 
 @pytest.mark.parametrize("B,ci,co,H,W,pad,bias", [(2, 32, 32, 32, 64, 0, True), (1, 48, 96, 16, 32, 1, False), (2, 128, 128, 64, 64, 0, True),
-                                                  (1, 320, 320, 32, 32, 1, True), (3, 16, 64, 48, 96, 0, True)])
+                                                  (1, 320, 320, 32, 32, 1, True), (3, 16, 64, 48, 96, 0, True),
+                                                  # the UNet's down-sampling launches of the step (K split: 80 / 192 workgroups alone)
+                                                  (8, 640, 640, 32, 32, 1, True), (8, 320, 320, 64, 64, 1, True)])
 def test_stride2_conv_vs_fp64(ops, B, ci, co, H, W, pad, bias):
     """The direct fp32-MFMA 3x3 / stride-2 convolution (diffusers Downsample2D: pad 0 = F.pad(x,(0,1,0,1)) + padding 0 as in
     the VAE encoder, pad 1 = padding 1 as in the UNet) against fp64; ragged channel groups (Cout = 96, 320) included."""
