@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--verify", default="auto", choices=["auto", "on", "off"],
                     help="host-drawn weights on BOTH legs and one 256^2 image through the oracle's reference-order CPU step and the "
                          "MI355X step: loss / gradient agreement goes into the line (auto: with the CPU baseline leg)")
+    ap.add_argument("--f32-split", default="auto", choices=["auto", "off"],
+                    help="auto: after the timed steps, time the same step with the split-bf16 flash-attention kernels (the "
+                         "`f32_split` key; sd* models at N = 1); off: skip it (profiling runs that window on the last steps)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-fuse-norms", action="store_true", help="A/B: keep ATen GroupNorm/SiLU in the frozen blocks")
@@ -720,7 +723,7 @@ def main():
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows, cv_folded = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         cv_forms = conv_step_forms(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         f32_split = None
-        if a.model.startswith("sd") and world == 1:
+        if a.model.startswith("sd") and world == 1 and a.f32_split != "off":
             # EXPERIMENT beside the line of record (never part of `value`): fp32-accurate matrix products on the bf16 matrix
             # cores by three-term operand splits.  (1) the step with the flash-attention forward routed through the split kernel
             # (the one kernel family where the split pays), timed like the line of record; (2) the two split kernels next to
@@ -740,8 +743,8 @@ def main():
                 cv_probe = split_conv_probe(ops, B, min(image_size, 512), max(5, a.kernel_iters // 6), dev)
                 f32_split = {"value": global_batch * a.steps / el_s, "ms_per_step": el_s / a.steps * 1e3, "unit": "images/sec",
                              "dtype": "f32 via 3 x bf16 operand split (6 products), fp32 accumulate",
-                             "what": "the same step with the flash-attention FORWARD of the d = 40 / 80 self-attention layers on "
-                                     "the split kernel (SKP_FLASH_SPLIT=1); everything else, incl. the attention backward and the "
+                             "what": "the same step with the self-attention of the 64^2 / 32^2 layers on the split kernels "
+                                     "(SKP_FLASH_SPLIT=1: forward at d = 40 / 80, backward at d = 40); everything else, incl. the "
                                      "convolutions, on the fp32 instructions",
                              "max_err_vs_fp64_ratio": fa_probe["max_err_vs_fp64_ratio"],
                              "flash_forward": fa_probe, "conv3x3": cv_probe,

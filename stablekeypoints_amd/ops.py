@@ -1056,12 +1056,22 @@ def conv3x3(x, weight, bias=None, residual=None):
     return Conv3x3Fn.apply(x, weight, bias, residual)
 
 
+GN_ONEPASS = os.environ.get("SKP_GN_ONEPASS", "1") != "0"      # mirrors the switch the library reads (csrc/skp_group_norm.hip)
+GN_ONEPASS_MAX_ROW = 16 * 1024 * 4                               # elements per (sample, group) row the one-pass forward holds
+
+
+def _stats_useful(cout: int, h: int, w: int, groups: int = 32) -> bool:
+    """Block statistics in a convolution's epilogue only pay where the GroupNorm that follows does not hold its rows in
+    registers anyway (the one-pass form computes exact statistics from the row it has loaded)."""
+    return not (GN_ONEPASS and cout % groups == 0 and (cout // groups) * h * w <= GN_ONEPASS_MAX_ROW)
+
+
 def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
     """The frozen blocks' 3x3 convolution (+ bias + residual): Winograd kernel where it is wanted, library
     convolution (and the fused bias+residual pass) otherwise."""
     frozen = not (weight.requires_grad or (bias is not None and bias.requires_grad))     # the kernels give no dW / db
     if frozen and x.is_cuda and x.dtype == torch.float32 and conv3x3_wanted(x.shape, weight.shape):
-        nblk = conv3x3_stats_blocks(x.shape, weight.shape) if want_stats else 0
+        nblk = conv3x3_stats_blocks(x.shape, weight.shape) if (want_stats and _stats_useful(weight.shape[0], x.shape[2], x.shape[3])) else 0
         if nblk:
             stats = torch.empty(x.shape[0], weight.shape[0], nblk, 2, device=x.device, dtype=torch.float32)
             y = Conv3x3Fn.apply(x, weight, bias, residual, stats)
@@ -1136,7 +1146,7 @@ def conv3x3_gn_silu(x, norm: torch.nn.GroupNorm, weight, off=None, bias=None, re
                 "skp_group_norm_coef_f32")
     U = _wino4_filters(weight, False)
     y = torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
-    nblk = conv3x3_stats_blocks(x.shape, weight.shape) if want_stats else 0
+    nblk = conv3x3_stats_blocks(x.shape, weight.shape) if (want_stats and _stats_useful(cout, H, W)) else 0
     stats = torch.empty(B, cout, nblk, 2, device=x.device, dtype=torch.float32) if nblk else None
     chunk = max(1, (2 ** 31 - 1) // (max(C, cout) * H * W * 4))          # rows per launch under the kernels' 2 GiB addressing limit
     for b0 in range(0, B, chunk):

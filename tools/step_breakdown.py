@@ -15,7 +15,7 @@ F32_MATRIX_PEAK_TF = 157.3
 
 CLASSES = [
     ("skp conv3x3 (Winograd stride 1 + direct stride 2)", ("skp_wino", "skp_conv_s2")),
-    ("skp flash attention (self + long-key cross)", ("skp_self_attn", "skp_fa2_")),
+    ("skp flash attention (self + long-key cross)", ("skp_self_attn", "skp_fa2_", "skp_fas_")),
     ("skp attention map fwd/bwd (north-star kernel)", ("skp_attn_map", "skp_map_")),
     ("skp fused GroupNorm+SiLU / bias+residual / add+LayerNorm", ("skp_group_norm", "skp_gn_", "skp_add_bias", "skp_add_ln")),
     ("skp cross-attn (T<=128) / selection / loss / small gemm / geglu / layout", ("skp_",)),
