@@ -112,11 +112,12 @@ def _context_kv_begin(unet, context):
         mods = [m for m in mods if m.to_k.bias is None and m.to_v.bias is None and not m.to_k.weight.requires_grad
                 and not m.to_v.weight.requires_grad and m.to_k.weight.shape[1] == context.shape[-1]
                 and "forward" not in m.to_k.__dict__ and "forward" not in m.to_v.__dict__]
-        plan = {"mods": mods, "used": None}
+        plan = {"mods": mods, "used": None, "ids": {id(m) for m in mods}}
         unet._skp_ctx_plan = plan
     mods = plan["mods"] if plan["used"] is None else [m for m in plan["mods"] if id(m) in plan["used"]]
     if plan["used"] is None:
         plan["used"] = set()
+    _CTX_KV["plan"] = plan
     groups = {}
     for m in mods:
         groups.setdefault(m.to_k.weight.shape[0], []).append(m)
@@ -133,9 +134,13 @@ def _context_kv_end():
 
 
 def _context_kv(module):
-    """(k, v) of `module` for the forward in flight, or None (no shared-context forward, or the layer was left out)."""
+    """(k, v) of `module` for the forward in flight, or None (no shared-context forward, or the layer was left out: it
+    projects for itself this time and is part of the batch from the next forward on)."""
     hit = _CTX_KV.get(id(module))
     if hit is None:
+        plan = _CTX_KV.get("plan")
+        if plan is not None and id(module) in plan["ids"]:
+            plan["used"].add(id(module))
         return None
     hit[2].add(id(module))
     return hit[0], hit[1]

@@ -369,6 +369,21 @@ def test_batched_context_projections_equal_per_layer_projections(monkeypatch):
         assert abs(got[0] - ref[0]) <= 1e-5 * abs(ref[0]) and abs(got[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-9
         torch.testing.assert_close(got[3], ref[3], rtol=1e-4, atol=1e-5 * ref[3].abs().max().item())
     assert not ptp_utils._CTX_KV                                   # nothing of a finished forward stays behind
+    # a FULL forward afterwards: the layers beyond the early exit project for themselves once and join the batch from then on
+    with torch.no_grad():
+        both = torch.cat([images.cuda(), tr(images.cuda(), theta=thetas)])
+        cg = ctx.clone().cuda()
+        outs = []
+        for _ in range(2):
+            _, pred = ptp_utils.find_pred_noise(ldm, both, cg, device=dev, noise=noise.cuda(), early_exit=False, controllers=controllers)
+            controller.reset()
+            outs.append(pred)
+        monkeypatch.setattr(ptp_utils, "CTX_KV_BATCHED", False)
+        _, pred_ref = ptp_utils.find_pred_noise(ldm, both, cg, device=dev, noise=noise.cuda(), early_exit=False, controllers=controllers)
+        controller.reset()
+    assert len(plan["used"]) == len(plan["mods"])
+    for p_ in outs:
+        torch.testing.assert_close(p_, pred_ref, rtol=1e-4, atol=1e-5 * pred_ref.abs().max().item())
 
 
 @pytest.mark.parametrize("N,C,H,W", [(8, 1280, 16, 16), (2, 320, 64, 64), (8, 640, 32, 32)])
