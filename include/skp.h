@@ -258,6 +258,11 @@ int skp_group_norm_fwd_f32(const float* x, const float* off, const float* gamma,
 int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma, const float* beta,
                            const float* dy, const float* mean, const float* rstd, float* dx, float* workspace,
                            int N, int C, int G, int HW, float eps, int silu, void* stream);
+/* The same plus `dadd` [N,C,HW]: dx = (input gradient of the norm) + dadd -- x feeds the norm AND its block's residual path
+ * (ResnetBlock2D / Transformer2DModel); the residual path's gradient is added here instead of by an add pass of its own. */
+int skp_group_norm_bwd_add_f32(const float* x, const float* off, const float* gamma, const float* beta,
+                               const float* dy, const float* mean, const float* rstd, float* dx, const float* dadd,
+                               float* workspace, int N, int C, int G, int HW, float eps, int silu, void* stream);
 
 /* out[n,c,p] = a[n,c,p] + b[n,c,p] + bias[c]  (ResnetBlock2D tail: shortcut + conv2 + conv2.bias in one pass). HW % 4 == 0. */
 int skp_add_bias_residual_f32(const float* a, const float* b, const float* bias, float* out, int N, int C, int HW,

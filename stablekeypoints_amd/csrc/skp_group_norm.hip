@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void skp_gn_bwd_apply_kernel(GNArgs a, const f
                                                                const float* __restrict__ mean_in,
                                                                const float* __restrict__ rstd_in,
                                                                const float* __restrict__ partial,
-                                                               float* __restrict__ dx) {
+                                                               float* __restrict__ dx, const float* __restrict__ dadd) {
     const int row = blockIdx.y, tid = threadIdx.x;
     const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
     const float mean = mean_in[row], rstd = rstd_in[row];
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void skp_gn_bwd_apply_kernel(GNArgs a, const f
             gz *= gam;
             r[e] = rstd * (gz - m1 - xh * m2);
         }
+        if (dadd) r += *(const f32x4*)(dadd + (size_t)row * a.L + i * 4);     // gradient of x's other use (fork entry)
         *(f32x4*)(dxr + i * 4) = r;
     }
 }
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(1024) void skp_gn_onepass_fwd_kernel(GNArgs a, floa
 
 template <int VPT>
 __global__ __launch_bounds__(1024) void skp_gn_onepass_bwd_kernel(GNArgs a, const float* __restrict__ dy, const float* __restrict__ mean_in,
-                                                                  const float* __restrict__ rstd_in, float* __restrict__ dx) {
+                                                                  const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                                  const float* __restrict__ dadd) {
     __shared__ float red[16];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n = row / a.G, g = row - n * a.G, Cg = a.C / a.G;
@@ -336,7 +338,11 @@ __global__ __launch_bounds__(1024) void skp_gn_onepass_bwd_kernel(GNArgs a, cons
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const int i = tid + 1024 * j;
-        if (i < q4) *(f32x4*)(dxr + (size_t)i * 4) = (gz[j] - m1 - xh[j] * m2) * rstd;
+        if (i < q4) {
+            f32x4 r = (gz[j] - m1 - xh[j] * m2) * rstd;
+            if (dadd) r += *(const f32x4*)(dadd + (size_t)row * a.L + (size_t)i * 4);
+            *(f32x4*)(dxr + (size_t)i * 4) = r;
+        }
     }
 }
 
@@ -368,14 +374,15 @@ static int gn_onepass_fwd(const GNArgs& a, float* y, float* mean, float* rstd, h
     return skp_launch_status();
 }
 
-static int gn_onepass_bwd(const GNArgs& a, const float* dy, const float* mean, const float* rstd, float* dx, hipStream_t st) {
+static int gn_onepass_bwd(const GNArgs& a, const float* dy, const float* mean, const float* rstd, float* dx, const float* dadd,
+                          hipStream_t st) {
     const dim3 grid(a.N * a.G), block(1024);
     switch (gn_onepass_vpt(a, true)) {
-        case 1: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<1>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
-        case 2: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<2>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
-        case 4: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<4>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
-        case 8: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<8>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
-        case 10: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<10>, grid, block, 0, st, a, dy, mean, rstd, dx); break;
+        case 1: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<1>, grid, block, 0, st, a, dy, mean, rstd, dx, dadd); break;
+        case 2: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<2>, grid, block, 0, st, a, dy, mean, rstd, dx, dadd); break;
+        case 4: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<4>, grid, block, 0, st, a, dy, mean, rstd, dx, dadd); break;
+        case 8: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<8>, grid, block, 0, st, a, dy, mean, rstd, dx, dadd); break;
+        case 10: hipLaunchKernelGGL(skp_gn_onepass_bwd_kernel<10>, grid, block, 0, st, a, dy, mean, rstd, dx, dadd); break;
         default: return -100;
     }
     return skp_launch_status();
@@ -491,16 +498,35 @@ extern "C" int skp_group_norm_coef_f32(const float* x, const float* off, const f
     return skp_launch_status();
 }
 
+static int gn_bwd_run(const float* x, const float* off, const float* gamma, const float* beta, const float* dy, const float* mean,
+                      const float* rstd, float* dx, const float* dadd, float* workspace, int N, int C, int G, int HW, float eps,
+                      int silu, void* stream);
+
 extern "C" int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma, const float* beta,
                                       const float* dy, const float* mean, const float* rstd, float* dx,
                                       float* workspace, int N, int C, int G, int HW, float eps, int silu,
                                       void* stream) {
+    return gn_bwd_run(x, off, gamma, beta, dy, mean, rstd, dx, nullptr, workspace, N, C, G, HW, eps, silu, stream);
+}
+
+// dx = (input gradient of the norm) + dadd: x feeds the norm AND something else (the residual path of its block); the
+// gradient of that other use rides in this kernel instead of an add pass of its own.  dadd [N,C,HW] (may alias nothing).
+extern "C" int skp_group_norm_bwd_add_f32(const float* x, const float* off, const float* gamma, const float* beta,
+                                          const float* dy, const float* mean, const float* rstd, float* dx, const float* dadd,
+                                          float* workspace, int N, int C, int G, int HW, float eps, int silu, void* stream) {
+    if (!dadd) return SKP_E_BADARG;
+    return gn_bwd_run(x, off, gamma, beta, dy, mean, rstd, dx, dadd, workspace, N, C, G, HW, eps, silu, stream);
+}
+
+static int gn_bwd_run(const float* x, const float* off, const float* gamma, const float* beta, const float* dy, const float* mean,
+                      const float* rstd, float* dx, const float* dadd, float* workspace, int N, int C, int G, int HW, float eps,
+                      int silu, void* stream) {
     GNArgs a{};
     int rc = gn_fill(a, x, off, gamma, beta, N, C, G, HW, eps, silu);
     if (rc) return rc;
     if (!dy || !mean || !rstd || !dx || !workspace) return SKP_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (gn_onepass_vpt(a, true)) return gn_onepass_bwd(a, dy, mean, rstd, dx, st);
+    if (gn_onepass_vpt(a, true)) return gn_onepass_bwd(a, dy, mean, rstd, dx, dadd, st);
     hipLaunchKernelGGL(skp_gn_bwd_stats_kernel, dim3(a.nsplit, N * G), dim3(256), 0, st, a, dy, mean, rstd, workspace);
     rc = skp_launch_status();
     if (rc) return rc;
@@ -508,7 +534,7 @@ extern "C" int skp_group_norm_bwd_f32(const float* x, const float* off, const fl
     if (blocks < 1) blocks = 1;
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(skp_gn_bwd_apply_kernel, dim3((unsigned)blocks, N * G), dim3(256), 0, st, a, dy, mean, rstd,
-                       (const float*)workspace, dx);
+                       (const float*)workspace, dx, dadd);
     return skp_launch_status();
 }
 

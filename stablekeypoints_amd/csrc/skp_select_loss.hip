@@ -393,4 +393,4 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 33; }
+extern "C" int skp_abi_version(void) { return 34; }

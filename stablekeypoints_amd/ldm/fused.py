@@ -28,7 +28,9 @@ def _resnet_forward(m: ResnetBlock2D):
         if ops.conv3x3_gn_fold_ok(x, m.norm1, m.conv1.weight):
             h = ops.conv3x3_gn_silu(x, m.norm1, m.conv1.weight, want_stats=True)
         else:
-            h = ops.group_norm_silu(x, m.norm1)                          # (statistics from x's producer when it left them)
+            # (statistics from x's producer when it left them); x' = x for the residual path below: its gradient is added
+            # inside norm1's input-gradient kernel
+            h, x = ops.group_norm_silu_fork(x, m.norm1)
             h = ops.conv3x3_auto(h, m.conv1.weight, want_stats=True)     # bias folded into norm2's offset
         off = _norm2_offset(m, x.shape[0], temb)
         bias = m.conv2.bias
@@ -117,7 +119,7 @@ def _transformer_forward(m: Transformer2DModel):
             return orig(x, context)
         if not ops.layout_supported(x):
             return orig(x, context)                  # the module's own forward knows both projection layouts
-        h = ops.group_norm_silu(x, m.norm, silu=False)
+        h, x = ops.group_norm_silu_fork(x, m.norm, silu=False)          # x' = x for the residual add at the end
         # token layout throughout: the 1x1 convolutions are nn.Linear over tokens (bias fused in the GEMM), the two
         # permutes are tiled transposes and the residual add rides on the way back
         t = ops.nchw_to_tokens(h)

@@ -611,7 +611,38 @@ class GroupNormSiLUFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+class GroupNormSiLUForkFn(torch.autograd.Function):
+    """(y, x') = (act(GroupNorm(x + off)), x): the norm of a block whose input ALSO feeds the block's residual path
+    (ResnetBlock2D: conv2(...) + x; Transformer2DModel: proj_out(...) + x).  x' is x itself; routing the residual path through
+    it hands BOTH gradients of x to this backward, where the residual path's gradient is added inside the norm's
+    input-gradient kernel (skp_group_norm_bwd_add_f32) instead of by an accumulation pass of autograd's."""
+
+    @staticmethod
+    def forward(ctx, x, off, gamma, beta, groups: int, eps: float, silu: bool, blocks=None):
+        y = GroupNormSiLUFn.forward(ctx, x, off, gamma, beta, groups, eps, silu, blocks)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dxp):
+        if dxp is None:
+            return GroupNormSiLUFn.backward(ctx, dy)
+        x, off_c, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, eps, silu, has_off = ctx.meta
+        Nn, C, Hh, Ww = x.shape
+        if dy is None:
+            return dxp, None, None, None, None, None, None, None
+        dy, dxp = _dev(dy, "dy"), _dev(dxp, "dx'")
+        dx = torch.empty_like(x)
+        ws = torch.empty(Nn * groups * 64 * 3, device=x.device, dtype=torch.float32)
+        N.check(N.lib().skp_group_norm_bwd_add_f32(x.data_ptr(), off_c.data_ptr() if has_off else None, gamma.data_ptr(),
+                                                   beta.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   dx.data_ptr(), dxp.data_ptr(), ws.data_ptr(), Nn, C, groups, Hh * Ww, eps,
+                                                   int(silu), _stream()), "skp_group_norm_bwd_add_f32")
+        return dx, None, None, None, None, None, None, None
+
+
 GN_FUSED_STATS = os.environ.get("SKP_GN_FUSED_STATS", "1") != "0"
+GN_FORK = os.environ.get("SKP_GN_FORK", "1") != "0"            # A/B switch
 
 
 def group_norm_silu(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
@@ -622,6 +653,18 @@ def group_norm_silu(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
                                or blocks[1] * blocks[2] != x.shape[2] * x.shape[3]):
         blocks = None
     return GroupNormSiLUFn.apply(x, off, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, blocks)
+
+
+def group_norm_silu_fork(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
+    """(group_norm_silu(x), x') with x' = x for the block's residual path: see GroupNormSiLUForkFn.  Without a gradient to
+    carry (or with the switch off) x' is x itself and nothing changes."""
+    if not (GN_FORK and torch.is_grad_enabled() and x.requires_grad):
+        return group_norm_silu(x, norm, off=off, silu=silu), x
+    blocks = getattr(x, "_skp_blocks", None) if GN_FUSED_STATS else None
+    if blocks is not None and (blocks[0].shape[0] != x.shape[0] or blocks[0].shape[1] != x.shape[1]
+                               or blocks[1] * blocks[2] != x.shape[2] * x.shape[3]):
+        blocks = None
+    return GroupNormSiLUForkFn.apply(x, off, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, blocks)
 
 
 # ---------------------------------------------------------------------------------------------

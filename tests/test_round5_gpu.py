@@ -414,3 +414,41 @@ def test_one_pass_group_norm_statistics_far_from_zero(N, C, H, W):
     torch.testing.assert_close(outs[0][0].cpu().double(), ref.detach(), rtol=2e-4, atol=2e-4)
     torch.testing.assert_close(outs[0][1].cpu().double(), xd.grad, rtol=1e-3, atol=2e-4 * xd.grad.abs().max().item())
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("N,C,H,W,silu,with_off", [(2, 320, 64, 64, True, False), (2, 1280, 16, 16, False, True), (1, 1920, 32, 32, True, True),
+                                                   (2, 128, 128, 128, True, False)])
+def test_group_norm_fork_adds_the_residual_gradient_in_kernel(N, C, H, W, silu, with_off):
+    """(y, x') = fork(x): y = GroupNorm(+SiLU)(x), x' = x for the block's residual path; the gradient of x is the norm's input
+    gradient PLUS the residual path's, added inside the norm's backward kernel (one-pass and two-kernel forms) -- against
+    plain autograd over the un-forked composition, bit for bit in the forward, to rounding in the gradient."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(N, C, H, W, generator=g).cuda()
+    off = torch.randn(N, C, generator=g).cuda() if with_off else None
+    norm = torch.nn.GroupNorm(32, C).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, generator=g)); norm.bias.copy_(torch.randn(C, generator=g))
+    for p_ in norm.parameters():
+        p_.requires_grad = False
+    w1, w2 = torch.randn(N, C, H, W, generator=g).cuda(), torch.randn(N, C, H, W, generator=g).cuda()
+    xa = x0.clone().requires_grad_(True)
+    y, xp = ops.group_norm_silu_fork(xa, norm, off=off, silu=silu)
+    assert type(y.grad_fn).__name__.startswith("GroupNormSiLUForkFn")
+    ((y * w1).sum() + (xp * xp * w2).sum()).backward()
+    xb = x0.clone().requires_grad_(True)
+    y2 = ops.group_norm_silu(xb, norm, off=off, silu=silu)
+    ((y2 * w1).sum() + (xb * xb * w2).sum()).backward()
+    assert torch.equal(y, y2) and torch.equal(xp, xa)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-6 * xb.grad.abs().max().item())
+    # only one of the two outputs used
+    xc = x0.clone().requires_grad_(True)
+    y3, xp3 = ops.group_norm_silu_fork(xc, norm, off=off, silu=silu)
+    (xp3 * w2).sum().backward()
+    torch.testing.assert_close(xc.grad, w2)
+    xd = x0.clone().requires_grad_(True)
+    y4, _ = ops.group_norm_silu_fork(xd, norm, off=off, silu=silu)
+    (y4 * w1).sum().backward()
+    xe = x0.clone().requires_grad_(True)
+    (ops.group_norm_silu(xe, norm, off=off, silu=silu) * w1).sum().backward()
+    assert torch.equal(xd.grad, xe.grad)
