@@ -335,6 +335,130 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_fwd_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Forward for SHORT key axes and wide heads (the 16^2 layers: N = 256, d = 160): the grid above is one four-wave workgroup
+// per CU there (64 (batch row, head) pairs x 4 query blocks = 256), one wave per SIMD, and a workgroup's eight 32-key tiles are a
+// serial chain of ~5 us each (2.4 us of MFMAs, then softmax, staging and a barrier that nothing overlaps): 47 us for 17 us of
+// matrix work.  Here the workgroup has EIGHT waves: waves 0-3 take the first half of the key tiles, waves 4-7 the second half,
+// for the SAME 64 queries (two waves per SIMD: one half's softmax / staging runs beside the other's MFMAs); each half keeps
+// its own running max / sum / output and its own single-buffered K | V tile (the next tile travels through registers
+// meanwhile), and the two partial results are merged through LDS at the end (flash-decoding's split over the key axis, inside
+// the workgroup: no second launch, fixed order, bit-reproducible).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512, 1) void skp_fa2_fwd_halves_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, float* __restrict__ out,
+                                                                   float* __restrict__ lse, int H, int N, int Nk, int kvb, float scale) {
+    using F = FA2<D>;
+    static_assert(D % 16 == 0, "the row sums are lane partials here");
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 halves][K | V][TILE]; the merge buffer lies over it
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+    const int half = wave >> 2, wq = wave & 3, htid = tid & 255;
+    const int b = blockIdx.z, h = blockIdx.y, C = H * D;
+    const int nbase = blockIdx.x * 64 + wq * 16;
+    const size_t hoff = (size_t)(kvb ? b : 0) * Nk * C + (size_t)h * D;
+    const float* kg = k + hoff;
+    const float* vg = v + hoff;
+    const float sl2 = scale * SKP_LOG2E;
+    const int ntiles = (Nk + F::KT - 1) / F::KT, nt0 = (ntiles + 1) / 2;
+    const int tfirst = half ? nt0 : 0, tcount = half ? ntiles - nt0 : nt0;     // this half's tiles; both halves loop nt0 times
+
+    f32x2 qf[1][F::D8];
+    const int n = nbase + i16;
+    {
+        const float* qrow = q + ((size_t)b * N + (n < N ? n : N - 1)) * C + h * D + 2 * g;
+#pragma unroll
+        for (int jj = 0; jj < F::D8; ++jj) qf[0][jj] = *(const f32x2*)(qrow + 8 * jj) * sl2;
+    }
+    f32x4 o[F::CT][1];
+#pragma unroll
+    for (int ct = 0; ct < F::CT; ++ct) o[ct][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lpart = 0.f;
+
+    FA2Stage<D> stg;
+    stg.init(C, htid);
+    float* Ks = smem + half * 2 * F::TILE;
+    float* Vs = Ks + F::TILE;
+    f32x4 kr[F::U], vr[F::U];
+    if (tcount > 0) {
+        fa2_fetch_tile<D>(kr, kg, C, tfirst * F::KT, Nk, stg, htid);
+        fa2_fetch_tile<D>(vr, vg, C, tfirst * F::KT, Nk, stg, htid);
+        fa2_put<D>(Ks, kr, stg);
+        fa2_put<D>(Vs, vr, stg);
+    }
+    __syncthreads();
+    for (int it = 0; it < nt0; ++it) {
+        const bool have = it < tcount, more = it + 1 < tcount;
+        const int kt0 = (tfirst + it) * F::KT;
+        if (more) {                                             // next tile of this half: in flight under this tile's MFMAs
+            fa2_fetch_tile<D>(kr, kg, C, kt0 + F::KT, Nk, stg, htid);
+            fa2_fetch_tile<D>(vr, vg, C, kt0 + F::KT, Nk, stg, htid);
+        }
+        if (have) {
+            f32x4 s[F::NKT][1];
+#pragma unroll
+            for (int kt = 0; kt < F::NKT; ++kt) s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fa2_rowdot<D, F::NKT, 1>(Ks, qf, s, i16, g);
+            if (kt0 + F::KT > Nk) {                             // ragged last tile (wave-uniform branch)
+                const int left = Nk - kt0;
+#pragma unroll
+                for (int kt = 0; kt < F::NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * kt + 4 * g + r >= left) s[kt][0][r] = -INFINITY;
+            }
+            float tm = fmaxf(fmaxf(s[0][0][0], s[0][0][1]), fmaxf(s[0][0][2], s[0][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < F::NKT; ++kt) tm = fmaxf(tm, fmaxf(fmaxf(s[kt][0][0], s[kt][0][1]), fmaxf(s[kt][0][2], s[kt][0][3])));
+            tm = fa2_max4(tm);
+            const float mn = fmaxf(mrun, tm);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mn);
+            mrun = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < F::NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[kt][0][r] = __builtin_amdgcn_exp2f(s[kt][0][r] - mn);
+                    rs += s[kt][0][r];
+                }
+            lpart = lpart * alpha + rs;
+#pragma unroll
+            for (int ct = 0; ct < F::CT; ++ct) o[ct][0] *= alpha;
+            fa2_colacc<D, F::NKT, 1>(Vs, s, o, i16, g);
+        }
+        __syncthreads();                                        // everyone is done reading the tiles
+        if (more) { fa2_put<D>(Ks, kr, stg); fa2_put<D>(Vs, vr, stg); }
+        __syncthreads();
+    }
+    // merge: the second half parks (o, m, l partial) in LDS, the first half combines in fixed order and writes
+    constexpr int MST = 4 * F::CT + 2;                          // floats per lane
+    float* mb = smem + (size_t)(wq * 64 + lane) * MST;
+    if (half == 1) {
+#pragma unroll
+        for (int ct = 0; ct < F::CT; ++ct) *(f32x4*)(mb + 4 * ct) = o[ct][0];
+        mb[4 * F::CT] = mrun;
+        mb[4 * F::CT + 1] = lpart;
+    }
+    __syncthreads();
+    if (half == 0) {
+        const float m1 = mb[4 * F::CT], l1 = mb[4 * F::CT + 1];
+        const float mn = fmaxf(mrun, m1);
+        const float a0 = __builtin_amdgcn_exp2f(mrun - mn), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - mn);
+        const float l = fa2_sum4(lpart * a0 + l1 * a1);
+        const float inv = 1.0f / l;
+        if (n < N) {
+            float* orow = out + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+            for (int ct = 0; ct < F::CT; ++ct) {
+                const f32x4 o1 = *(const f32x4*)(mb + 4 * ct);
+                *(f32x4*)(orow + 16 * ct + 4 * g) = (o[ct][0] * a0 + o1 * a1) * inv;
+            }
+            if (g == 0) lse[((size_t)b * H + h) * N + n] = (mn + __builtin_amdgcn_logf(l)) * SKP_LN2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Backward: two kernels built from the same three tile products (deterministic, no atomics, no transposes).
 //   dQ kernel   lane = query (as the forward): per key tile  S^T = K.Q^T, dP^T = V.dO^T, dS = P (dP - D),
 //               dQ^T[c][n] += sum_t K[t][c] dS[n][t]; also writes D[n] = rowsum(dO * O) for the second kernel.
@@ -842,6 +966,22 @@ static int fa2_launch_fwd(const float* q, const float* k, const float* v, float*
     return skp_launch_status();
 }
 
+template <int D>
+static int fa2_launch_fwd_halves(const float* q, const float* k, const float* v, float* out, float* lse, int B, int H, int N, int Nk,
+                                 int kvb, float scale, hipStream_t st) {
+    using F = FA2<D>;
+    constexpr size_t tiles = (size_t)4 * F::TILE * sizeof(float), merge = (size_t)256 * (4 * F::CT + 2) * sizeof(float);
+    const size_t lds = tiles > merge ? tiles : merge;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)skp_fa2_fwd_halves_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(skp_fa2_fwd_halves_kernel<D>, dim3((N + 63) / 64, H, B), dim3(512), lds, st, q, k, v, out, lse, H, N, Nk, kvb, scale);
+    return skp_launch_status();
+}
+
 // returns -100 when this head size is not built here (the caller falls back to the first-generation kernels)
 int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, float* lse, int B, int Bk, int H, int N,
                 int Nk, int d, float scale, void* stream) {
@@ -869,7 +1009,11 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
             if (opt == 4) FA2_FWD(80, 2, 2, 4);
             FA2_FWD(80, 2, 2, 0);
         case 160:                                               // 16^2 layers (N = 256): 16 queries per wave, 32-key tiles
-            FA2_FWD(160, 1, 1, 0);
+            // few workgroups, short key axis: the key tiles split over two wave sets of one workgroup (variant 3: the one-set kernel)
+            if (variant != 3 && variant != 4 && Nk >= 4 * FA2<160>::KT && (long)((N + 63) / 64) * H * B <= 1024)
+                return fa2_launch_fwd_halves<160>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
+            if (variant == 4) FA2_FWD(160, 1, 1, 0);
+            FA2_FWD(160, 1, 1, 4);
         default: return -100;
     }
 #undef FA2_FWD
@@ -983,7 +1127,8 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
             if (variant == 2) FA2_BWD(80, 2, 1, 2, 1, true);
             FA2_BWD(80, 2, 1, 2, 1, false);
         case 160:
-            FA2_BWD(160, 1, 1, 1, 1, false);
+            if (variant == 4) FA2_BWD(160, 1, 1, 1, 1, false);
+            FA2_BWD(160, 1, 1, 1, 1, true);
         default: return -100;
     }
 #undef FA2_BWD
