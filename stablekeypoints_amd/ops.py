@@ -1313,17 +1313,8 @@ _QKV_CACHE = {}
 
 
 def _qkv_stack(wq, wk, wv):
-    """[3, C, C] stack of the three frozen projection weights of a self-attention block (made once per block; checked
-    against the parameters' versions and identities like the other derived buffers of frozen weights)."""
-    import weakref
-    key = (wq.data_ptr(), wk.data_ptr(), wv.data_ptr(), tuple(wq.shape), wq.device)
-    hit = _QKV_CACHE.get(key)
-    ver = (wq._version, wk._version, wv._version)
-    if hit is not None and hit[0] == ver and hit[2]() is wq:
-        return hit[1]
-    w3 = torch.stack([wq.detach(), wk.detach(), wv.detach()]).contiguous()
-    _QKV_CACHE[key] = (ver, w3, weakref.ref(wq))
-    return w3
+    """[3, C, C] stack of the three frozen projection weights of a self-attention block (made once per block)."""
+    return weight_stack([wq, wk, wv])
 
 
 def weight_stack(ws):
@@ -1336,6 +1327,8 @@ def weight_stack(ws):
     if hit is not None and hit[0] == ver and hit[2]() is ws[0]:
         return hit[1]
     w3 = torch.stack([w.detach() for w in ws]).contiguous()
+    for dead in [k_ for k_, v_ in _QKV_CACHE.items() if v_[2]() is None]:     # stacks of models that are gone
+        del _QKV_CACHE[dead]
     _QKV_CACHE[key] = (ver, w3, weakref.ref(ws[0]))
     return w3
 

@@ -535,3 +535,25 @@ def test_group_indices_order_is_loader_independent(tmp_path):
     got = list(GroupLoader(ds, _group_indices(a, 10, None, 2, 2, 0, 2), "cpu", workers=4))
     assert [(it, idx) for it, idx, _ in got] == r0
     assert all(torch.equal(im, torch.stack([ds[i]["img"] for i in idx])) for _, idx, im in got)
+
+
+def test_weight_stack_is_cached_per_parameter_list_and_follows_versions():
+    """Stacked copies of frozen projection weights (q | k | v of a self-attention block, k / v of the cross-attention layers of one
+    width): made once, re-made when a parameter is written, dropped when its model is gone."""
+    import gc
+    import torch
+    from stablekeypoints_amd import ops
+    a, b = torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(4, 3))
+    s1 = ops.weight_stack([a, b])
+    assert s1.shape == (2, 4, 3) and torch.equal(s1[1], b.detach())
+    assert ops.weight_stack([a, b]) is s1
+    with torch.no_grad():
+        b.mul_(2.0)                                               # version bump: the stack must follow
+    s2 = ops.weight_stack([a, b])
+    assert s2 is not s1 and torch.equal(s2[1], b.detach())
+    n = len(ops._QKV_CACHE)
+    del a, b, s1, s2
+    gc.collect()
+    c = torch.nn.Parameter(torch.randn(2, 2))
+    ops.weight_stack([c, c])                                      # inserting prunes entries whose owner is gone
+    assert len(ops._QKV_CACHE) <= n
