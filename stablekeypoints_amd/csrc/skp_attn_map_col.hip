@@ -59,6 +59,7 @@ struct ColLayer {
     float* dS;                       // [B,H,s*s,ldt]
     float* Psel;                     // [B,H,s*s,CL_KMAX] the selected tokens' +p g part
     int l;                           // layer index (lse / dot)
+    int Psel_s;                      // the layer's side s (dot kernel)
 };
 struct ColArgs {
     ColLayer ly[SKP_MAX_LAYERS];
@@ -79,8 +80,12 @@ __device__ __forceinline__ float cl_pair_swap(float v) {      // value of the ot
 }
 
 // K2 = k/2 rows per group = lanes per tap-sharing group (4: quads, 2: pairs); R = map side = threads; SEL: selected-token launch.
-template <int K2, int R, bool SEL>
+// INL (natural launch only): the selected tokens of a chunk are handled INSIDE the natural chunk -- dot comes complete from
+// skp_map_bwd_dot_kernel, a selected token's f is p (g / (L H) - dot) with its gradient row loaded under a wave-uniform branch --
+// so there is no selected-token sweep, no side buffer and no second dot plane.
+template <int K2, int R, bool SEL, bool INL = false>
 __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
+    static_assert(!(SEL && INL), "INL is a form of the natural launch");
     constexpr int RR = R * R, s = R / (2 * K2), E = (K2 == 2) ? 2 : 1;
     constexpr int VG = K2 * s * CL_TS;           // floats of one V buffer (K2 rows)
     constexpr int XB = (R * E + 1) * CL_PS;      // floats of one exchange buffer (+1: the zero slot list padding points at)
@@ -156,17 +161,28 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
     const i32x4 drs0 = skp_make_rsrc(a.dotp + plane + (SEL ? (size_t)ch * dot_plane : 0), RR * 4u);
     const i32x4 drs1 = skp_make_rsrc(a.dotp + plane + dot_plane, RR * 4u);
     const i32x4 grs = skp_make_rsrc(a.G + (size_t)b * a.K * RR, (unsigned)a.K * RR * 4u);      // this batch row's K gradient rows
-    const int dvo1 = a.nsel > 1 ? tid * 4 : SKP_OOB;
+    const int dvo1 = (!INL && a.nsel > 1) ? tid * 4 : SKP_OOB;
     float* out_g = SEL ? ly.Psel + ((size_t)(b * H + h) * s * s) * CL_KMAX + k0
                        : ly.dS + ((size_t)(b * H + h) * s * s) * a.ldt + k0;
     const int out_ld = SEL ? CL_KMAX : a.ldt;
     __syncthreads();
     // natural launch: the selected slot (or -1) of each token this thread writes -- its +p g part is added on the way out
+    int kslot[CL_TC];                            // INL: selected slot (or -1) of token k0 + t, wave-uniform
+#pragma unroll
+    for (int t = 0; t < CL_TC; ++t) {
+        kslot[t] = -1;
+        if (INL) {
+            int ks = -1;
+            for (int k = 0; k < a.K; ++k) ks = (selk[k] == k0 + t) ? k : ks;
+            // byte offset of the token's gradient plane, or one past every plane (it goes into the VECTOR offset: the range check sees that one)
+            kslot[t] = __builtin_amdgcn_readfirstlane(ks >= 0 ? ks * RR * 4 : CL_KMAX * RR * 4);
+        }
+    }
     int ksel[GO];
 #pragma unroll
     for (int oo = 0; oo < GO; ++oo) {
         ksel[oo] = -1;
-        if (!SEL) {
+        if (!SEL && !INL) {
             const int t = k0 + (tid + oo * R) % CL_TC;
             for (int k = 0; k < a.K; ++k) ksel[oo] = (selk[k] == t) ? k : ksel[oo];
         }
@@ -239,7 +255,7 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
             lse_n[r] = skp_buf_load_f32(lrs, tid * 4, so, 0);
             if (!SEL) {   // second part only when K > 8: otherwise an out-of-range offset (returns 0), no branch in the sweep
                 d0_n[r] = skp_buf_load_f32(drs0, tid * 4, so, 0);
-                d1_n[r] = skp_buf_load_f32(drs1, dvo1, so, 0);
+                d1_n[r] = INL ? 0.f : skp_buf_load_f32(drs1, dvo1, so, 0);
             }
         }
     };
@@ -262,6 +278,12 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
             const float* vrow = Vg + buf * VG + r * s * CL_TS;
             const float lse = lse_r[r], nd = nd_r[r];
             float dsum = 0.f;
+            // INL: a token's multiplier of p is -dot, plus g / (L H) when it is a selected one (wave-uniform test; formed where
+            // it is used: eight more live registers in this loop spill the accumulator window)
+            // (branch-free: a token that is not selected reads past the descriptor, which returns 0 without a memory access)
+            auto mult = [&](int t) -> float {
+                return fmaf(skp_buf_load_f32(grs, tid * 4 + kslot[t], y * R * 4, 0), a.inv_lh, nd);
+            };
 #pragma unroll
             for (int q = 0; q < CL_TC / 4; ++q) {
                 const f32x4 t0 = *(const f32x4*)(vrow + cx[0] + 4 * q);
@@ -277,7 +299,7 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (SEL) f[e] *= gk[r & 1][4 * q + e];
-                    f[e] *= nd;
+                    f[e] *= INL ? mult(4 * q + e) : nd;
                     if (SEL) dsum += f[e];
                 }
                 const f32x2 f01 = {f[0], f[1]}, f23 = {f[2], f[3]};
@@ -330,7 +352,7 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
                 for (int e = 1; e < CL_LUSE; ++e) sum += v[e];
                 const size_t row = (size_t)cy * s + c;
                 const int ks = GO == 1 ? ksel[0] : (oo ? ksel[GO - 1] : ksel[0]);
-                if (!SEL && ks >= 0) sum += ly.Psel[((size_t)(b * H + h) * s * s + row) * CL_KMAX + ks];
+                if (!SEL && !INL && ks >= 0) sum += ly.Psel[((size_t)(b * H + h) * s * s + row) * CL_KMAX + ks];
                 out_g[row * out_ld + t] = sum;
             }
         }
@@ -394,12 +416,68 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
 
 // ONE launch per pass for all layers: the layers of the k = 8 class come first (nl4 of them), then the k = 4 class; a
 // launch per class left the smaller class (640 workgroups of two waves at the step's shape) alone on the chip.
-template <int R, bool SEL>
+template <int R, bool SEL, bool INL = false>
 __global__ __launch_bounds__(R, SEL ? CL_WAVES_SEL : CL_WAVES_NAT) void skp_map_bwd_col_kernel(ColArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int li = (int)(blockIdx.x / a.B) / a.nch / a.H;
-    if (li < a.nl4) col_body<4, R, SEL>(a, smem);
-    else col_body<2, R, SEL>(a, smem);
+    if (li < a.nl4) col_body<4, R, SEL, INL>(a, smem);
+    else col_body<2, R, SEL, INL>(a, smem);
+}
+
+// dot[b, l, h, y, x] = (1 / (L H)) sum_{k < K} p_k g_k   with p_k = exp2(bicubic(S_l)[sel_k] - lse): the softmax backward's row
+// term, needed before any token's gradient can be formed.  Row-parallel (no sweep): a workgroup of R threads (lane = column)
+// takes DR up-res rows of one (batch row, layer, head): vertical taps of the K selected tokens into LDS (DR x s x K values), then
+// the horizontal taps, exp2, the product with the gradient rows.  B * L * H * R / DR workgroups, independent.
+#ifndef CL_DR
+#define CL_DR 4
+#endif
+template <int R>
+__global__ __launch_bounds__(R) void skp_map_bwd_dot_kernel(ColArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [CL_DR][s][CL_KMAX]
+    constexpr int RR = R * R;
+    const int tid = threadIdx.x, H = a.H;
+    const int b = blockIdx.x % a.B;
+    int rest = blockIdx.x / a.B;
+    const int yb = rest % (R / CL_DR);
+    rest /= (R / CL_DR);
+    const int h = rest % H, li = rest / H;
+    const ColLayer ly = a.ly[li];
+    const int s = (int)ly.Psel_s;
+    const float ratio = (float)s / (float)R;
+    const float* Sb = ly.S + ((size_t)(b * H + h) * s * s) * a.ldt;
+    const int items = CL_DR * s * a.K;
+    for (int idx = tid; idx < items; idx += R) {
+        const int k = idx % a.K, c = (idx / a.K) % s, r = idx / (a.K * s);
+        int cy[4]; float wy[4];
+        skp_cubic_taps(yb * CL_DR + r, ratio, s, cy, wy);
+        const int tok = (int)a.sel[(size_t)b * a.K + k];
+        float v = wy[0] * Sb[((size_t)cy[0] * s + c) * a.ldt + tok];
+        v = fmaf(wy[1], Sb[((size_t)cy[1] * s + c) * a.ldt + tok], v);
+        v = fmaf(wy[2], Sb[((size_t)cy[2] * s + c) * a.ldt + tok], v);
+        v = fmaf(wy[3], Sb[((size_t)cy[3] * s + c) * a.ldt + tok], v);
+        smem[(r * s + c) * CL_KMAX + k] = v;
+    }
+    __syncthreads();
+    int cx[4]; float wx[4];
+    skp_cubic_taps(tid, ratio, s, cx, wx);
+    const size_t plane = ((size_t)b * a.L * H + ly.l * H + h) * RR;
+    const float* gb = a.G + (size_t)b * a.K * RR;
+#pragma unroll
+    for (int r = 0; r < CL_DR; ++r) {
+        const int y = yb * CL_DR + r;
+        const float lse = a.lse[plane + (size_t)y * R + tid];
+        const float* v0 = smem + (r * s + cx[0]) * CL_KMAX;
+        const float* v1 = smem + (r * s + cx[1]) * CL_KMAX;
+        const float* v2 = smem + (r * s + cx[2]) * CL_KMAX;
+        const float* v3 = smem + (r * s + cx[3]) * CL_KMAX;
+        float acc = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            float val = wx[0] * v0[k];
+            val = fmaf(wx[1], v1[k], val); val = fmaf(wx[2], v2[k], val); val = fmaf(wx[3], v3[k], val);
+            acc = fmaf(__builtin_amdgcn_exp2f(val - lse), gb[(size_t)k * RR + (size_t)y * R + tid], acc);
+        }
+        a.dotp[plane + (size_t)y * R + tid] = acc * a.inv_lh;
+    }
 }
 
 int col_k2(int R, int s) {
@@ -455,13 +533,33 @@ extern "C" int skp_attn_map_bwd_col_f32(const float* const* S, float* const* dS,
         for (int l = 0; l < L; ++l) {
             if (col_k2(R, s[l]) != k2) continue;
             ColLayer& y = a.ly[a.nl++];
-            y.S = S[l]; y.dS = dS[l]; y.Psel = Psel[l]; y.l = l;
+            y.S = S[l]; y.dS = dS[l]; y.Psel = Psel[l]; y.l = l; y.Psel_s = s[l];
             const int e = k2 == 2 ? 2 : 1;
             const size_t need = (2 * (size_t)k2 * s[l] * CL_TS + 2 * ((size_t)R * e + 1) * CL_PS + 4 * (size_t)R +
                                  (size_t)s[l] * CL_LUSE + CL_KMAX) * sizeof(float);
             lds = need > lds ? need : lds;
         }
         if (k2 == 4) a.nl4 = a.nl;
+    }
+    // Route: the inline form costs every natural chunk ~20 % (eight more loads per row, most of them past the descriptor) and saves
+    // the selected-token sweep: measured 344 -> 313 us at T = 77 (10 chunks), 1 379 -> 1 512 us at T = 500 (63 chunks) => up to
+    // 16 chunks.  SKP_MAP_COL_DOT=0 / 1 forces the two-sweep / the inline form.
+    static const int inl_env = [] { const char* e = getenv("SKP_MAP_COL_DOT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool inl = inl_env >= 0 ? inl_env == 1 : nt / CL_TC <= 16;
+    if (inl) {     // dot by its own row-parallel kernel, then ONE sweep launch: natural chunks with their selected tokens inline
+        int smax = 0;
+        for (int l = 0; l < L; ++l) smax = s[l] > smax ? s[l] : smax;
+        const dim3 dgrid((unsigned)((long)B * (R / CL_DR) * H * a.nl)), block(R);
+        const size_t dlds = (size_t)CL_DR * smax * CL_KMAX * sizeof(float);
+        if (R == 128) hipLaunchKernelGGL((skp_map_bwd_dot_kernel<128>), dgrid, block, dlds, st, a);
+        else hipLaunchKernelGGL((skp_map_bwd_dot_kernel<256>), dgrid, block, dlds, st, a);
+        int rc = skp_launch_status();
+        if (rc) return rc;
+        a.nch = nt / CL_TC;
+        const dim3 grid((unsigned)((long)B * a.nch * H * a.nl));
+        if (R == 128) hipLaunchKernelGGL((skp_map_bwd_col_kernel<128, false, true>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((skp_map_bwd_col_kernel<256, false, true>), grid, block, lds, st, a);
+        return skp_launch_status();
     }
     for (int pass = 0; pass < 2; ++pass) {                      // 0: selected tokens (dot + their part), 1: natural chunks
         a.nch = pass == 0 ? nsel : nt / CL_TC;
