@@ -178,6 +178,9 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
             kslot[t] = __builtin_amdgcn_readfirstlane(ks >= 0 ? ks * RR * 4 : CL_KMAX * RR * 4);
         }
     }
+    bool has_sel = false;                        // wave-uniform
+#pragma unroll
+    for (int t = 0; t < CL_TC; ++t) has_sel = has_sel || (INL && kslot[t] != CL_KMAX * RR * 4);
     int ksel[GO];
 #pragma unroll
     for (int oo = 0; oo < GO; ++oo) {
@@ -263,7 +266,8 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
 #pragma unroll
         for (int r = 0; r < K2; ++r) { lse_r[r] = lse_n[r]; nd_r[r] = SEL ? a.inv_lh : -(d0_n[r] + d1_n[r]); }
     };
-    auto rows = [&](int gg, int buf) {
+    auto rows = [&](int gg, int buf, auto withg_c) {
+        constexpr bool WITHG = decltype(withg_c)::value;      // INL: this chunk holds a selected token (else the plain row code)
         float gk[2][CL_TC];
         auto g_load = [&](int y, int slot) {             // slots k >= K lie past the descriptor: 0 (the range check sees the vector offset)
 #pragma unroll
@@ -299,7 +303,7 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (SEL) f[e] *= gk[r & 1][4 * q + e];
-                    f[e] *= INL ? mult(4 * q + e) : nd;
+                    f[e] *= (INL && WITHG) ? mult(4 * q + e) : nd;
                     if (SEL) dsum += f[e];
                 }
                 const f32x2 f01 = {f[0], f[1]}, f23 = {f[2], f[3]};
@@ -380,7 +384,8 @@ __device__ __forceinline__ void col_body(const ColArgs& a, float* smem) {
         const bool more = gg + 1 < 2 * s;
         if (PF) { if (more) { ln_issue(gg + 1); v_issue(gg + 1); } }
         else { ln_issue(gg); ln_take(); }
-        rows(gg, gg & 1);
+        if (INL && has_sel) rows(gg, gg & 1, std::true_type{});
+        else rows(gg, gg & 1, std::false_type{});
         if (!PF && more) v_issue(gg + 1);
         if (more) v_store(gg + 1, (gg + 1) & 1);
         if (PF && more) ln_take();
@@ -541,11 +546,11 @@ extern "C" int skp_attn_map_bwd_col_f32(const float* const* S, float* const* dS,
         }
         if (k2 == 4) a.nl4 = a.nl;
     }
-    // Route: the inline form costs every natural chunk ~20 % (eight more loads per row, most of them past the descriptor) and saves
-    // the selected-token sweep: measured 344 -> 313 us at T = 77 (10 chunks), 1 379 -> 1 512 us at T = 500 (63 chunks) => up to
-    // 16 chunks.  SKP_MAP_COL_DOT=0 / 1 forces the two-sweep / the inline form.
-    static const int inl_env = [] { const char* e = getenv("SKP_MAP_COL_DOT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    const bool inl = inl_env >= 0 ? inl_env == 1 : nt / CL_TC <= 16;
+    // Route: the inline form everywhere it was measured (B = 8, R = 128, 16^2 x 3 + 32^2 layers: T = 77 344 -> 268 us, T = 128
+    // 428 -> 394, T = 500 1 379 -> 1 217; 2 rows 213 -> 128; R = 256 746 -> 624).  With the row code instantiated twice (chunks
+    // with / without a selected token) the sweep kernel needs 156 registers and no scratch (the two-sweep natural kernel: 240 + 12
+    // bytes).  SKP_MAP_COL_DOT=0 restores the two-sweep form (A/B).
+    static const bool inl = [] { const char* e = getenv("SKP_MAP_COL_DOT"); return !(e && e[0] == '0'); }();
     if (inl) {     // dot by its own row-parallel kernel, then ONE sweep launch: natural chunks with their selected tokens inline
         int smax = 0;
         for (int l = 0; l < L; ++l) smax = s[l] > smax ? s[l] : smax;
