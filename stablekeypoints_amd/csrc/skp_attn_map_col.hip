@@ -17,10 +17,12 @@
 // The vertical interpolation the forward needs (V phase) is done per group for the group's K2 rows only (3 KB of LDS,
 // double-buffered, the next group's loads in flight under the current group's rows).
 //
-// Two launches: the K selected tokens first (chunks of 8 selected slots, logits gathered by token id): they give
-// dot = sum_k p_k g_k per (layer, head, pixel) -- stored, 4 bytes per pixel like lse -- and the +p_k g_k part of the gradient
-// (a small side buffer); then the natural 8-token chunks with f_t = -p_t dot, which write dS and add the selected tokens'
-// part on the way out.  HBM-side: lse + dot re-read per chunk from L2 / MALL, dS written once; nothing staged.
+// Launches (round 5): dot = sum_k p_k g_k / (L H) per (layer, head, pixel) by a row-parallel kernel (skp_map_bwd_dot_kernel: the
+// K selected tokens only, no sweep), then ONE sweep launch over the natural 8-token chunks: f_t = p_t (g_t / (L H) - dot) for a
+// selected token -- its gradient row is loaded through a descriptor offset that lies past the buffer for every other token, so
+// the row code is branch-free --, f_t = -p_t dot otherwise; chunks without a selected token run the plain row code (wave-uniform
+// choice per group).  dS is written once, nothing is staged.  The two-sweep form it replaces (selected tokens first: dot + their
+// part in a side buffer, then the natural chunks) stays behind SKP_MAP_COL_DOT=0.
 //
 // Shapes served (skp_attn_map_bwd_col_ok): R in {128, 256}, every layer R = k s with k in {4, 8} and s >= 8, T <= 1024, K <= 16
 // -- the SD-1.x path at feature_upsample_res 128 / 256; everything else keeps the other routes.
@@ -59,7 +61,7 @@ struct ColLayer {
     float* dS;                       // [B,H,s*s,ldt]
     float* Psel;                     // [B,H,s*s,CL_KMAX] the selected tokens' +p g part
     int l;                           // layer index (lse / dot)
-    int Psel_s;                      // the layer's side s (dot kernel)
+    int s;                           // the layer's side (dot kernel)
 };
 struct ColArgs {
     ColLayer ly[SKP_MAX_LAYERS];
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(R) void skp_map_bwd_dot_kernel(ColArgs a) {
     rest /= (R / CL_DR);
     const int h = rest % H, li = rest / H;
     const ColLayer ly = a.ly[li];
-    const int s = (int)ly.Psel_s;
+    const int s = ly.s;
     const float ratio = (float)s / (float)R;
     const float* Sb = ly.S + ((size_t)(b * H + h) * s * s) * a.ldt;
     const int items = CL_DR * s * a.K;
@@ -538,7 +540,7 @@ extern "C" int skp_attn_map_bwd_col_f32(const float* const* S, float* const* dS,
         for (int l = 0; l < L; ++l) {
             if (col_k2(R, s[l]) != k2) continue;
             ColLayer& y = a.ly[a.nl++];
-            y.S = S[l]; y.dS = dS[l]; y.Psel = Psel[l]; y.l = l; y.Psel_s = s[l];
+            y.S = S[l]; y.dS = dS[l]; y.Psel = Psel[l]; y.l = l; y.s = s[l];
             const int e = k2 == 2 ? 2 : 1;
             const size_t need = (2 * (size_t)k2 * s[l] * CL_TS + 2 * ((size_t)R * e + 1) * CL_PS + 4 * (size_t)R +
                                  (size_t)s[l] * CL_LUSE + CL_KMAX) * sizeof(float);
