@@ -397,6 +397,9 @@ int skp_token_stats_f32(const float* M, int T, int R, int num_subjects, float si
  * cand: i64[n_cand], sel: i64[top_k].  Limits: T <= 1024, n_cand <= 64, 2 <= top_k <= n_cand. */
 int skp_select_tokens(const float* kl, const int32_t* argmax_t, int T, int R, int n_cand, int top_k,
                       int64_t* cand, int64_t* sel, void* stream);
+/* n images per launch: kl, argmax_t [n,T] -> cand [n,n_cand], sel [n,top_k] (one workgroup per image, same selection). */
+int skp_select_tokens_batched(const float* kl, const int32_t* argmax_t, int n, int T, int R, int n_cand, int top_k,
+                              int64_t* cand, int64_t* sel, void* stream);
 
 /* Sharpening + equivariance losses and their unit gradients for the K selected tokens
  * (optimize.py:157-206):

@@ -135,10 +135,15 @@ __device__ __forceinline__ float skp_dist(float ay, float ax, float by, float bx
     return __fsqrt_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)));
 }
 
+// blockIdx.x = image of a batch (skp_select_tokens_batched): every pointer advances by its per-image stride
 __global__ __launch_bounds__(256) void skp_select_kernel(const float* __restrict__ kl,
                                                          const int32_t* __restrict__ argmax_t, int T, int R,
                                                          int n_cand, int top_k, int64_t* __restrict__ cand_out,
                                                          int64_t* __restrict__ sel_out) {
+    kl += (size_t)blockIdx.x * T;
+    argmax_t += (size_t)blockIdx.x * T;
+    cand_out += (size_t)blockIdx.x * n_cand;
+    sel_out += (size_t)blockIdx.x * top_k;
     __shared__ float s_kl[SKP_SEL_MAXT];
     __shared__ int s_cand[SKP_SEL_MAXC];
     __shared__ float s_ly[SKP_SEL_MAXC], s_lx[SKP_SEL_MAXC];
@@ -218,6 +223,15 @@ extern "C" int skp_select_tokens(const float* kl, const int32_t* argmax_t, int T
     if (T > SKP_SEL_MAXT || n_cand > SKP_SEL_MAXC || n_cand > T || top_k < 2 || top_k > n_cand) return SKP_E_RANGE;
     hipLaunchKernelGGL(skp_select_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kl, argmax_t, T, R, n_cand,
                        top_k, cand, sel);
+    return skp_launch_status();
+}
+
+// n images at once: kl, argmax_t [n,T]; cand [n,n_cand], sel [n,top_k] -- one workgroup per image, the same code path
+extern "C" int skp_select_tokens_batched(const float* kl, const int32_t* argmax_t, int n, int T, int R, int n_cand, int top_k,
+                                         int64_t* cand, int64_t* sel, void* stream) {
+    if (!kl || !argmax_t || !cand || !sel || n <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
+    if (T > SKP_SEL_MAXT || n_cand > SKP_SEL_MAXC || n_cand > T || top_k < 2 || top_k > n_cand) return SKP_E_RANGE;
+    hipLaunchKernelGGL(skp_select_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, kl, argmax_t, T, R, n_cand, top_k, cand, sel);
     return skp_launch_status();
 }
 
@@ -393,4 +407,4 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 34; }
+extern "C" int skp_abi_version(void) { return 35; }

@@ -414,6 +414,9 @@ def fused_losses(M, Mt, sel, argmax, theta, sigma: float, num_subjects: int = 1)
     return LossesFn.apply(M, Mt, sel, argmax, invert_affine(theta), float(sigma), int(num_subjects))
 
 
+MAP_LOSSES_BATCHED = os.environ.get("SKP_MAP_LOSSES_BATCHED", "1") != "0"     # A/B switch: statistics / selection per image
+
+
 class MapLossesFn(torch.autograd.Function):
     """One node for `maps -> selection -> losses` of a group of images (optimize.py:347-414 for n images x 2 views), so that
     the map backward sees the gradient as it is -- K selected rows per batch row -- instead of a dense [B,T,R,R] tensor:
@@ -452,11 +455,35 @@ class MapLossesFn(torch.autograd.Function):
         nchunk = (R * R + 1023) // 1024
         partial = torch.empty(n, 2, K, nchunk, device=dev, dtype=torch.float32)
         lib, st = N.lib(), _stream()
+        # token statistics and the selection of ALL images in three launches (one workgroup per (image, token) / per image: the
+        # per-image launches were 77 workgroups of 40 us each, twelve of them per step); per-token results are what the
+        # per-image calls give, bit for bit
+        strategy = meta["strategy"]
+        batched = (strategy in ("gaussian", "entropy", "consistent") and T <= SELECT_MAX_TOKENS and n_cand <= SELECT_MAX_CANDIDATES
+                   and K >= 2 and MAP_LOSSES_BATCHED)
+        if batched:
+            flat = M.reshape(B * T, R, R)
+            st_all = token_stats(flat[:n * T], num_subjects=ns, sigma=sigma, want_kl=strategy == "gaussian",
+                                 want_entropy=strategy == "entropy")
+            am_all = st_all[0].reshape(ns, n, T).permute(1, 0, 2).contiguous()                  # [n, ns, T]
+            if strategy == "gaussian":
+                score_all = st_all[1].reshape(n, T)
+            elif strategy == "entropy":
+                score_all = st_all[2].reshape(n, T)
+            else:
+                score_all = torch.arange(T, device=dev, dtype=torch.float32).repeat(n, 1)
+            amt_all, _ = token_stats(flat[n * T:], num_subjects=1, sigma=sigma, want_kl=False)  # [1, n*T]
+            cand_all = torch.empty(n, n_cand, device=dev, dtype=torch.int64)
+            N.check(lib.skp_select_tokens_batched(score_all.contiguous().data_ptr(), amt_all.data_ptr(), n, T, R, n_cand, K,
+                                                  cand_all.data_ptr(), sel_all.data_ptr(), st), "skp_select_tokens_batched")
         for i in range(n):
-            am, score = meta["score_fn"](M[i], meta["strategy"], ns, sigma)
-            am_t, _ = token_stats(M[n + i], num_subjects=1, sigma=sigma, want_kl=False)
-            _, sel_i = select_tokens(score, am_t[0], R, n_cand, K)
-            sel_all[i].copy_(sel_i)
+            if batched:
+                am = am_all[i]
+            else:
+                am, score = meta["score_fn"](M[i], strategy, ns, sigma)
+                am_t, _ = token_stats(M[n + i], num_subjects=1, sigma=sigma, want_kl=False)
+                _, sel_i = select_tokens(score, am_t[0], R, n_cand, K)
+                sel_all[i].copy_(sel_i)
             th, _keep = N.float_array(invert_affine(meta["thetas"][i]))
             N.check(lib.skp_losses_fwd_f32(M[i].data_ptr(), M[n + i].data_ptr(), sel_all[i].data_ptr(), K, T, R,
                                            am.data_ptr(), ns, sigma, th, partial[i].data_ptr(), g_sharp[i].data_ptr(),

@@ -452,3 +452,35 @@ def test_group_norm_fork_adds_the_residual_gradient_in_kernel(N, C, H, W, silu, 
     xe = x0.clone().requires_grad_(True)
     (ops.group_norm_silu(xe, norm, off=off, silu=silu) * w1).sum().backward()
     assert torch.equal(xd.grad, xe.grad)
+
+
+@pytest.mark.parametrize("strategy", ["gaussian", "entropy", "consistent"])
+def test_batched_token_statistics_and_selection_equal_the_per_image_calls(strategy, monkeypatch):
+    """Token statistics of all images in one launch, of all affine copies in another, the selection of all images in a third
+    (skp_select_tokens_batched): the same selections, loss sums and q / k gradients as the per-image launches, bit for bit
+    (ops.MapLossesFn on fixed hooked-layer inputs: every kernel on this path is deterministic)."""
+    from oracle import ref_path as R
+    from stablekeypoints_amd import ops
+    from stablekeypoints_amd.optimize import token_order
+    g = torch.Generator().manual_seed(21)
+    n, T, H, Rr = 3, 21, 8, 128
+    dims = [(16, 1280), (16, 1280), (32, 640)]
+    thetas = [R.affine_matrix(7.0 * (i - 1), 0.9, (0.1 * i, -0.05)).reshape(-1).tolist() for i in range(n)]
+    qs0 = [torch.randn(2 * n, s_ * s_, c, generator=g).cuda() for s_, c in dims]
+    ks0 = [torch.randn(1, T, c, generator=g).cuda() for _, c in dims]
+    meta = dict(R=Rr, heads=H, scales=[(c // H) ** -0.5 for _, c in dims], thetas=thetas, sigma=2.0, num_subjects=1,
+                strategy=strategy, n_cand=12, top_k=5, score_fn=token_order)
+    got = []
+    for mode in (False, True):
+        monkeypatch.setattr(ops, "MAP_LOSSES_BATCHED", mode)
+        qs = [q.clone().requires_grad_(True) for q in qs0]
+        ks = [k.clone().requires_grad_(True) for k in ks0]
+        flat = []
+        for q, k in zip(qs, ks):
+            flat += [q, k]
+        sh, eq, sel = ops.MapLossesFn.apply(meta, *flat)
+        (3.0 * sh + 7.0 * eq).backward()
+        got.append([sh.detach().clone(), eq.detach().clone(), sel.clone()] + [t.grad.clone() for t in qs + ks])
+    for a_, b_ in zip(got[0], got[1]):
+        assert torch.equal(a_, b_)
+    assert got[0][2].shape == (n, 5) and len(set(got[0][2][0].tolist())) == 5
