@@ -61,9 +61,6 @@ def parse():
     ap.add_argument("--conv-log", default="", help="write the per-launch list of conv_step_accounting to this JSON file")
     ap.add_argument("--cpu-image-size", type=int, default=512)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the best of a short sweep over {32,64,128} (16, 8 when 32 wins)")
-    ap.add_argument("--emulated-f32", action="store_true",
-                    help="EXPERIMENT (separate line, never the bench of record): frozen nn.Linear GEMMs on the bf16 matrix "
-                         "cores with three-term operand splits (tools/csrc/skp_gemm_x3.hip)")
     ap.add_argument("--cache-latents", action="store_true",
                     help="EXPERIMENT (separate line, never the bench of record): latents of the un-warped views kept per dataset image "
                          "(optimize.py cache_latents); the 16-image synthetic set then skips half the VAE work on every timed step")
@@ -79,7 +76,6 @@ def parse():
                          "`f32_split` key; sd* models at N = 1); off: skip it (profiling runs that window on the last steps)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
-    ap.add_argument("--no-fuse-norms", action="store_true", help="A/B: keep ATen GroupNorm/SiLU in the frozen blocks")
     return ap.parse_args()
 
 
@@ -219,43 +215,6 @@ def conv_roofline(ops, B, image_size, iters, device):
     units = 8 * ((((B * (image_size // 4) ** 2 + 15) // 16) + 7) // 8) * (co // 128)
     grid_threads = min(units, 256) * 256                         # 128-channel form: persistent, one workgroup per CU
     return t, direct, nbytes, grid_threads, B, folded
-
-
-def split_conv_probe(ops, B, image_size, iters, device):
-    """The round-5 experiment next to the kernel of record: the same 128 -> 128 launch on the bf16 matrix cores with three-term
-    operand splits (csrc/skp_conv_wino4s.hip, six products per fp32 product, fp32 accumulate) -- plain forms of both kernels,
-    interleaved rounds -- and the two kernels' errors against an fp64 convolution on a 128^2 crop of the same data.  The
-    step does NOT run on it (it is no faster: profiles/r05_conv_split.md); the key records that on the bench's own box."""
-    g = torch.Generator(device="cpu").manual_seed(2)
-    ci = co = 128
-    B = min(B, max(1, (2 ** 31 - 1) // (ci * image_size * image_size * 4)))
-    x = torch.randn(B, ci, image_size, image_size, generator=g).to(device)
-    w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).to(device)
-    U4, Us = ops._wino4_filters(w, False), ops._wino4s_filters(w, False)
-    y = torch.empty(B, co, image_size, image_size, device=device)
-    f32 = lambda: ops._conv3x3_f4_raw(x, U4, None, co, out=y)
-    spl = lambda: ops._conv3x3_f4s_raw(x, Us, None, co, out=y)
-    for _ in range(4):
-        f32(); spl()
-    times = {"f32": [], "split": []}
-    for _ in range(3):
-        for name, fn in (("f32", f32), ("split", spl)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                fn()
-            e1.record(); torch.cuda.synchronize()
-            times[name].append(e0.elapsed_time(e1) / iters * 1e3)
-    xs = x[:1, :, :min(128, image_size), :min(128, image_size)].contiguous()
-    ref = torch.nn.functional.conv2d(xs.double(), w.double(), padding=1)
-    e32 = (ops._conv3x3_f4_raw(xs, U4, None, co, split=False).double() - ref).abs().max().item()
-    esp = (ops._conv3x3_f4s_raw(xs, Us, None, co, split=False).double() - ref).abs().max().item()
-    t32, tsp = sorted(times["f32"])[1], sorted(times["split"])[1]
-    return {"what": f"128 -> 128 channels at {image_size}^2, {B} rows, plain forms: fp32-instruction kernel vs the split-bf16 kernel",
-            "kernel": "skp_wino4s_conv_kernel (v_mfma_f32_16x16x32_bf16, 3 x bf16 terms per operand, 6 products, fp32 accumulate)",
-            "dtype": "f32 via 3 x bf16 operand split, fp32 accumulate", "fp32_kernel_us": t32, "split_kernel_us": tsp,
-            "speedup": t32 / tsp, "max_err_vs_fp64_ratio": esp / e32, "max_err_vs_fp64": {"fp32_kernel": e32, "split_kernel": esp},
-            "on_path_of_record": False, "status": "measured negative (target was >= 1.4x): stage accounting in profiles/r05_conv_split.md"}
 
 
 def split_flash_probe(ops, B, iters, device):
@@ -617,8 +576,6 @@ def main():
     # host threads: N ranks share the box's cores (the Python driver is the only CPU work of a rank)
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // max(1, world))))
     from stablekeypoints_amd import ops, _native
-    if a.emulated_f32:
-        ops.EMULATED_F32 = True                                  # read by fuse_norms when the frozen blocks are patched
     from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
     from stablekeypoints_amd.optimize import SyntheticImages, default_args, group_step
     from stablekeypoints_amd.optimize_token import load_ldm
@@ -629,7 +586,7 @@ def main():
         a.cpu_image_size = image_size
 
     t_build = time.time()
-    cpu_stats = None
+    cpu_stats, t_cpu = None, 0.0
     want_cpu = a.cpu_baseline in ("on", "full", "sample") or (a.cpu_baseline == "auto" and world == 1 and a.model == "sd15")
     want_verify = a.verify == "on" or (a.verify == "auto" and want_cpu)
     ldm_cpu = None
@@ -637,7 +594,9 @@ def main():
         # the CPU leg gets its own host-side instance (seeded host draw)
         ldm_cpu, _, _ = load_ldm("cpu", a.model, feature_upsample_res=a.res)
         if want_cpu:
+            t_cpu = time.time()
             cpu_stats = cpu_baseline(ldm_cpu, a)
+            t_cpu = time.time() - t_cpu
     # frozen weights are drawn on this rank's GPU (seeded: identical on every rank; no N x 3.4 GB of host-side init)
     ldm, controllers, _ = load_ldm(dev, a.model, feature_upsample_res=a.res, init_on_device=True)
     controller = controllers[dev]
@@ -657,11 +616,9 @@ def main():
     if a.channels_last:
         ldm.unet.to(memory_format=torch.channels_last)
         ldm.vae.to(memory_format=torch.channels_last)
-    if a.no_fuse_norms:
-        raise SystemExit("--no-fuse-norms: load_ldm always fuses on a GPU; use SKP_CONV3X3=lib for the conv A/B")
     from stablekeypoints_amd import tuning
     gemm_tuned = tuning.enable()
-    t_build = time.time() - t_build
+    t_build = time.time() - t_build - t_cpu            # model construction, weight draw, verify leg (not the CPU baseline)
 
     if a.scaling == "strong":
         if a.global_batch % world:
@@ -740,14 +697,13 @@ def main():
                 el_s = time.perf_counter() - t0s
                 ops.FLASH_SPLIT = False
                 fa_probe = split_flash_probe(ops, B, max(5, a.kernel_iters // 6), dev)
-                cv_probe = split_conv_probe(ops, B, min(image_size, 512), max(5, a.kernel_iters // 6), dev)
                 f32_split = {"value": global_batch * a.steps / el_s, "ms_per_step": el_s / a.steps * 1e3, "unit": "images/sec",
                              "dtype": "f32 via 3 x bf16 operand split (6 products), fp32 accumulate",
                              "what": "the same step with the self-attention of the 64^2 / 32^2 layers on the split kernels "
                                      "(SKP_FLASH_SPLIT=1: forward at d = 40 / 80, backward at d = 40); everything else, incl. the "
                                      "convolutions, on the fp32 instructions",
                              "max_err_vs_fp64_ratio": fa_probe["max_err_vs_fp64_ratio"],
-                             "flash_forward": fa_probe, "conv3x3": cv_probe,
+                             "flash_forward": fa_probe,
                              "on_path_of_record": False}
             except Exception as e:                                # noqa: BLE001 -- an experiment key never takes the line of record down
                 ops.FLASH_SPLIT = False
@@ -802,14 +758,16 @@ def main():
                                    "strong: the global batch is fixed (global_batch images per optimizer step), each rank "
                                    "processes global_batch / N of them"),
             "vs_baseline": None,
-            "dtype": "f32-emulated (bf16x3 nn.Linear GEMMs, everything else f32)" if a.emulated_f32 else "f32",
+            "dtype": "f32",
             "data": "synthetic",
             **({"experiment": "cache_latents: the un-warped views' latents are reused from the first epoch over the "
                               f"{len(data)}-image synthetic set (half of each step's VAE work skipped); NOT the bench of record"}
                if a.cache_latents else {}),
-            "config": {"workload": f"{cfg_name}: {a.model} architecture UNet+VAE (seeded synthetic weights), "
-                                   f"{image_size}x{image_size}, batch {per_rank} images/rank/step x 2 views, "
-                                   f"T={a.tokens} tokens x {width}, R={a.res}, top_k={a.top_k} of {a.candidates}, fp32 end to end",
+            "config": {"workload": f"{cfg_name}: T={a.tokens} R={a.res} K={a.top_k}/{a.candidates} {a.model} {image_size}^2 "
+                                   f"{per_rank} img/rank x 2 views fp32",
+                       "workload_detail": f"{a.model} architecture UNet+VAE (seeded synthetic weights), {image_size}x{image_size}, batch "
+                                          f"{per_rank} images/rank/step x 2 views, T={a.tokens} tokens x {width}, R={a.res}, "
+                                          f"top_k={a.top_k} of {a.candidates}, fp32 end to end",
                        "global_batch": global_batch, "images_per_rank": per_rank, "tokens": a.tokens, "embedding_dim": width,
                        "feature_upsample_res": a.res, "parallelism": f"dp{world}",
                        "kept_across_steps": "functions of the frozen weights and the fixed timestep only: transformed convolution "
@@ -861,7 +819,7 @@ def main():
             "f32_split": f32_split,
             "traffic_live_kernels": sorted(live) if live else None,
             "cpu_baseline": cpu_stats, "verify": verify, "collective_check": coll,
-            "loss": float(last[0]), "build_s": t_build, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
+            "loss": float(last[0]), "setup_s": t_build, "cpu_baseline_s": t_cpu, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
             "weights_init": weights_init,
         }
         if line["roofline"]["traffic"]:

@@ -44,6 +44,14 @@ extern "C" {
 /* ABI version; bumped on any signature change. */
 int skp_abi_version(void);
 
+/* Developer overrides of launch plans, for tests/ and tools/ only (the product path never calls them; the library reads no
+ * environment variables).  Keys: "wino_split" (force the K split of the F(4x4,3x3) launches), "wino_raw_max_tiles" (widen the
+ * raw-filter form's gate), "map_bands" (band count of the token-major map backward), "fa2_two_kernel_bwd" (1: the two-kernel
+ * flash backward at the fused form's shapes), "gn_fold_max_cout".  value 0 = the library's own choice.  Process-global, not
+ * thread-safe.  Returns 0 / the value, SKP_E_RANGE for an unknown key. */
+int skp_tune_set(const char* key, int value);
+int skp_tune_get(const char* key);
+
 /* Batched NT GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 fma chain):
  *   C[z0,z1][m,n] = alpha * sum_k A[z0,z1][m,k] * B[z0,z1][n,k]          z0<Z0, z1<Z1
  * with arbitrary element strides (sXm,sXk / sXn,sXk) and two batch strides per operand
@@ -254,6 +262,9 @@ int skp_self_attn_bwd_f32(const float* q, const float* k, const float* v, const 
 int skp_group_norm_fwd_f32(const float* x, const float* off, const float* gamma, const float* beta, float* y,
                            float* mean, float* rstd, float* workspace, int N, int C, int G, int HW, float eps,
                            int silu, void* stream);
+/* 1 when skp_group_norm_fwd_f32 serves this shape with its one-pass form (the (sample, group) row held in registers, exact
+ * statistics, one launch): a producer then need not leave block statistics behind (skp_conv3x3_f4_stats_f32). */
+int skp_group_norm_onepass_ok(int N, int C, int G, int HW);
 /* dx [N,C,HW] = d loss / d x given dy (gamma/beta/off are frozen on this path). workspace as above. */
 int skp_group_norm_bwd_f32(const float* x, const float* off, const float* gamma, const float* beta,
                            const float* dy, const float* mean, const float* rstd, float* dx, float* workspace,
@@ -307,22 +318,6 @@ int skp_conv3x3_f4_filter_f32(const void* w, void* U, int Cout, int Cin, int fli
 int64_t skp_conv3x3_f4_workspace(int B, int Cin, int Cout, int H, int W);
 int skp_conv3x3_f4_f32(const void* x, const void* U, const void* bias, const void* residual, void* y, void* workspace,
                        int B, int Cin, int Cout, int H, int W, void* stream);
-
-/* The Winograd F(4x4,3x3) convolution on the BF16 matrix cores with three-term operand splits (skp_conv_wino4s.hip): fp32 in /
- * out / accumulate; every fp32 operand of the transform-domain products is the exact sum of three bf16 terms h + m + l, the six
- * products h.h + h.m + m.h + h.l + l.h + m.m run on v_mfma_f32_16x16x32_bf16 (6 / 16 of the fp32 instructions' matrix time).  bf16
- * keeps the fp32 exponent range: as accurate as skp_conv3x3_f4_f32 at any input scale (profiles/r05_conv_split.md).  Same role
- * on the path as skp_conv3x3_f4_f32 (the frozen 3x3 convolutions, ptp_utils.py:227-229, 289-304); OPT-IN (the line of record
- * stays on the fp32 instructions).  Shapes: Cin % 16 == 0, Cout % 64 == 0, H, W % 4 == 0 (skp_conv3x3_f4s_ok; else SKP_E_RANGE).
- * Us: 36 * Cin * Cout * 3 bf16 from skp_conv3x3_f4s_filter_f32 (flip_transpose as skp_conv3x3_filter_f32).  workspace:
- * skp_conv3x3_f4s_workspace() bytes for the K-split partials (NULL forces an unsplit launch).  stats: optional
- * [B][Cout][skp_conv3x3_f4s_stats_blocks()][2] = {mean, sum (y - mean)^2} per 16-tile block (0 blocks = not available). */
-int skp_conv3x3_f4s_ok(int B, int Cin, int Cout, int H, int W);
-int skp_conv3x3_f4s_filter_f32(const void* w, void* Us, int Cout, int Cin, int flip_transpose, void* stream);
-int64_t skp_conv3x3_f4s_workspace(int B, int Cin, int Cout, int H, int W);
-int skp_conv3x3_f4s_stats_blocks(int B, int Cin, int Cout, int H, int W);
-int skp_conv3x3_f4s_f32(const void* x, const void* Us, const void* bias, const void* residual, void* y, void* workspace,
-                        float* stats, int B, int Cin, int Cout, int H, int W, void* stream);
 
 /* Output statistics for the GroupNorm that follows a convolution (diffusers ResnetBlock2D: conv1 -> norm2, conv2 + shortcut
  * -> the next block's norm1 [third party]): the convolution epilogues leave per-(image, channel, pixel-block) sums of their

@@ -15,13 +15,16 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKP_LIB_PATH: another BUILD of the same library (same-box A/B of two kernel versions, tools/ab_build.py); never a fallback
 LIB_PATH = os.environ.get("SKP_LIB_PATH") or os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> argtypes   (restype is always int)
 SIGNATURES = {
     "skp_abi_version": [],
+    "skp_tune_set": [C.c_char_p, _i],
+    "skp_tune_get": [C.c_char_p],
+    "skp_group_norm_onepass_ok": [_i, _i, _i, _i],
     "skp_gemm_nt_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i,
                         _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f, _vp],
     "skp_qk_logits_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
@@ -71,11 +74,6 @@ SIGNATURES = {
     "skp_flash_attn_bwd_split_ok": [_i, _i, _i, _i, _i, _i],
     "skp_flash_attn_bwd_split_workspace": [_i, _i, _i, _i, _i, _i],
     "skp_flash_attn_bwd_split_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "skp_conv3x3_f4s_ok": [_i, _i, _i, _i, _i],
-    "skp_conv3x3_f4s_filter_f32": [_vp, _vp, _i, _i, _i, _vp],
-    "skp_conv3x3_f4s_workspace": [_i, _i, _i, _i, _i],
-    "skp_conv3x3_f4s_stats_blocks": [_i, _i, _i, _i, _i],
-    "skp_conv3x3_f4s_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "skp_conv3x3_f4r_ok": [_i, _i, _i, _i, _i],
     "skp_conv3x3_f4r_filter_f32": [_vp, _vp, _i, _i, _i, _vp],
     "skp_conv3x3_f4r_workspace": [_i, _i, _i, _i, _i],
@@ -141,8 +139,6 @@ def lib():
 LAB_PATH = os.environ.get("SKP_LAB_PATH") or os.path.join(os.path.dirname(_HERE), "tools", "csrc", "libskp_lab.so")
 LAB_SIGNATURES = {
     "skp_probe_mfma_f32": [_i, _i, _vp, _vp, _vp],
-    "skp_gemm_x3_split_f32": [_vp, _vp, _i, _i, _i, _vp],
-    "skp_gemm_x3_nt_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _vp],
 }
 _lab = None
 
@@ -182,3 +178,8 @@ def int_array(vals):
 def float_array(vals):
     arr = (C.c_float * len(vals))(*[float(v) for v in vals])
     return C.cast(arr, C.POINTER(C.c_float)), arr
+
+
+def tune(key: str, value: int) -> None:
+    """Developer override of a launch plan (tests / tools; include/skp.h: skp_tune_set).  0 restores the library's choice."""
+    check(lib().skp_tune_set(key.encode(), int(value)), f"skp_tune_set({key})")

@@ -24,7 +24,6 @@
 //                 transpose + gather (deterministic, no atomics) -> dV[y][seg][c][t] in HBM
 //   second backward kernel: vertical adjoint dS[cy][c][t] = sum_y Wy(y,cy) sum_seg dV[y][seg][c][t]
 #include "skp_common.h"
-#include <stdlib.h>
 
 #ifndef SKP_MAP_VBATCH
 #define SKP_MAP_VBATCH 3
@@ -40,7 +39,6 @@ struct MapArgs {
     int L, B, H, T, R;
     int TH, TW, segs, smax;        // tile rows, tile width, segments per row, max layer side
     int vt_floats;                 // floats of the Vt buffer
-    int TH2, TW2, segs2, vt2_floats;   // geometry of the 128-pixel tiles (two-lanes-per-pixel kernels)
     float inv_lh;
     // token-group extension (T > 128): the launch covers tokens [t0, t0+T) of a wider problem
     int ldt;                       // row stride (floats) of S / dS rows (>= NT of this launch)
@@ -237,302 +235,6 @@ __global__ __launch_bounds__(256) void skp_attn_map_fwd_kernel(MapArgs a, float*
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (t < NT - 16 || t < T) M[(size_t)b * a.m_bstride + (size_t)t * RR + p] = acc[t >> 1][t & 1] * a.inv_lh;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Forward, two lanes per pixel (opt-in variant, SKP_MAP_LANES=2).  Same algorithm as skp_attn_map_fwd_kernel, but the token row of
-// a pixel is split over lane l (tokens [0, NT/2)) and lane l^32 (tokens [NT/2, NT)): 40+40 registers per lane
-// at T=77 instead of 80+80 => ~110 VGPRs => 4 waves/SIMD instead of 2, which is what hides the LDS-return and
-// barrier waits that leave the VALU pipe 63 % busy in the one-lane-per-pixel kernel (profiles/).  The softmax
-// needs two cross-lane exchanges per (layer, head).  Tiles are 128 pixels (wave = 32 pixels x 2 halves).
-struct Tile2 { int y0, seg, ry, x, th_eff; bool valid; };
-
-__device__ __forceinline__ Tile2 skp_tile2(const MapArgs& a, int blk, int tid) {
-    Tile2 t;
-    const int lin = (tid >> 6) * 32 + (tid & 31);              // pixel of this lane inside the 128-pixel tile
-    if (a.R <= 128) {
-        t.y0 = blk * a.TH2; t.seg = 0;
-        t.ry = lin / a.R; t.x = lin - t.ry * a.R;
-        t.th_eff = (a.R - t.y0 < a.TH2) ? a.R - t.y0 : a.TH2;
-        t.valid = t.ry < t.th_eff;
-    } else {
-        t.y0 = blk / a.segs2; t.seg = blk - t.y0 * a.segs2;
-        t.ry = 0; t.x = t.seg * 128 + lin; t.th_eff = 1;
-        t.valid = t.x < a.R;
-    }
-    if (!t.valid) { t.ry = 0; t.x = (a.R <= 128) ? 0 : a.R - 1; }
-    return t;
-}
-
-template <int NT, int MODE>
-__global__ __launch_bounds__(256, (NT <= 96 ? 3 : 2)) void skp_attn_map_fwd2_kernel(MapArgs a, float* __restrict__ M,
-                                                                float* __restrict__ lse_out,
-                                                                const float* __restrict__ lse_in) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 4, TPL = NT / 2, NP = TPL / 2;      // tokens per lane, token pairs per lane
-    constexpr int HB = 4;                                       // heads per V phase: one barrier pair per HB heads
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int half = (tid >> 5) & 1, toff = half * TPL;
-    const int R = a.R, T = a.T, H = a.H, RR = R * R;
-    const Tile2 tl = skp_tile2(a, blockIdx.y, tid);
-    const int p = (tl.y0 + tl.ry) * R + tl.x;
-    float* Vt = smem;
-    int* tab_cy = (int*)(smem + (size_t)HB * a.vt2_floats);
-    float* tab_wy = (float*)(tab_cy + a.TH2 * 4);
-
-    f32x2 acc[NP];
-#pragma unroll
-    for (int u = 0; u < NP; ++u) acc[u] = f32x2{0.f, 0.f};
-
-    int lh = 0;
-    for (int l = 0; l < a.L; ++l) {
-        const int s = a.s[l];
-        const float ratio = (float)s / (float)R;
-        int cx[4]; float wx[4];
-        skp_cubic_taps(tl.x, ratio, s, cx, wx);
-        int base[4];
-        f32x2 w2[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { base[i] = (tl.ry * s + cx[i]) * TS + toff; w2[i] = f32x2{wx[i], wx[i]}; }
-        __syncthreads();                                       // previous layer done with the tables
-        if (tid < tl.th_eff) {
-            int cy[4]; float wy[4];
-            skp_cubic_taps(tl.y0 + tid, ratio, s, cy, wy);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
-        }
-        const int rc = tl.th_eff * s;
-        for (int h0 = 0; h0 < H; h0 += HB) {
-          const int nh = (H - h0 < HB) ? H - h0 : HB;
-          __syncthreads();                                     // tables ready / previous H phases done
-          {                                                    // V phase of nh heads at once (independent loads)
-            constexpr int Q = NT / 4;
-            const float inv_s = 1.0f / (float)s;
-            const int per = rc * Q, items = nh * per;
-            const float* S0 = a.S[l] + ((size_t)(b * H + h0) * s * s) * a.ldt;
-#pragma unroll 2
-            for (int it = tid; it < items; it += 256) {
-                const int hb = it / per, rem = it - hb * per;
-                const int r = rem / Q, q4 = rem - r * Q;
-                const int row = (int)(((float)r + 0.5f) * inv_s);
-                const int c = r - row * s;
-                const float* Sg = S0 + (size_t)hb * s * s * a.ldt;
-                f32x4 av = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const f32x4 v = *(const f32x4*)(Sg + ((size_t)(tab_cy[row * 4 + jj] * s + c)) * a.ldt + q4 * 4);
-                    av += tab_wy[row * 4 + jj] * v;
-                }
-                *(f32x4*)(Vt + (size_t)hb * a.vt2_floats + r * TS + q4 * 4) = av;
-            }
-          }
-          __syncthreads();
-          for (int hb = 0; hb < nh; ++hb, ++lh) {
-            const float* Vh = Vt + (size_t)hb * a.vt2_floats;
-            f32x2 sv[NP];
-            float m = -INFINITY;
-            constexpr int UB = 2;
-#pragma unroll
-            for (int u0 = 0; u0 < NP; u0 += UB) {
-                f32x2 tv[4][UB];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int k = 0; k < UB; ++k) tv[i][k] = *(const f32x2*)(Vh + base[i] + 2 * (u0 + k));
-                f32x2 v[UB];
-#pragma unroll
-                for (int k = 0; k < UB; ++k) v[k] = w2[0] * tv[0][k];
-#pragma unroll
-                for (int i = 1; i < 4; ++i)
-#pragma unroll
-                    for (int k = 0; k < UB; ++k) v[k] = w2[i] * tv[i][k] + v[k];
-#pragma unroll
-                for (int k = 0; k < UB; ++k) {
-                    const int u = u0 + k;
-                    if (2 * u >= TPL - 16) {                    // pads only among the last 16 tokens (upper half)
-                        if (toff + 2 * u >= T) v[k][0] = -INFINITY;
-                        if (toff + 2 * u + 1 >= T) v[k][1] = -INFINITY;
-                    }
-                    sv[u] = v[k];
-                }
-                m = fmaxf(m, fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1])));
-            }
-            const size_t li = ((size_t)b * a.L * H + lh) * RR + p;
-            if (MODE == 2) {                                   // probabilities against the GLOBAL log-sum-exp
-                const float lse = tl.valid ? lse_in[li] : 0.f;
-#pragma unroll
-                for (int u = 0; u < NP; ++u) {
-                    const f32x2 e = sv[u] - lse;
-                    acc[u] += f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-                }
-                continue;
-            }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));               // the partner lane holds the other half of the row
-            f32x2 sum4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-            for (int u = 0; u < NP; ++u) {
-                const f32x2 e = sv[u] - m;
-                sv[u] = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-                sum4[u & 3] += sv[u];
-            }
-            const f32x2 sum2 = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-            float sum = sum2[0] + sum2[1];
-            sum += __shfl_xor(sum, 32, 64);
-            if (MODE == 0) {
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int u = 0; u < NP; ++u) acc[u] = sv[u] * inv + acc[u];
-            }
-            if (tl.valid && half == 0) lse_out[li] = m + __builtin_amdgcn_logf(sum);
-          }
-        }
-    }
-    if (tl.valid && MODE != 1) {
-#pragma unroll
-        for (int t = 0; t < TPL; ++t)
-            if (toff + t < T) M[(size_t)b * a.m_bstride + (size_t)(toff + t) * RR + p] = acc[t >> 1][t & 1] * a.inv_lh;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Forward, MFMA H phase (opt-in variant).  The VALU kernel above reads 4 taps x 4 B from LDS per output and is
-// LDS-bandwidth bound (ablation in profiles/).  Here the horizontal interpolation of a 16-pixel block is the
-// matrix product  D[t][x] = sum_c V[t][c] * Wx[c][x]  on v_mfma_f32_16x16x4_f32 (exact fp32 fma chain):
-//   A[i=t][k=c] = Vt[row][c][t]   ONE ds_read_b32 per MFMA (256 outputs)  -> 1 B of LDS per output
-//   B[k=c][j=x] = Wx[c][x]        the block's (<= 8 column) bicubic weights, in registers per layer
-//   D: lane (x = lane&15) holds tokens 16*tt + 4*(lane>>4) + r  -> the softmax over tokens is in-register
-//      plus two cross-lane exchanges (lane^16, lane^32).
-// A wave owns 4 blocks of 16 consecutive pixels; requires R % 16 == 0 and s/R <= 1/4 (<= 8 columns per block).
-template <int NT, int MODE>
-__global__ __launch_bounds__(256) void skp_attn_map_fwd_mfma_kernel(MapArgs a, float* __restrict__ M,
-                                                                    float* __restrict__ lse_out,
-                                                                    const float* __restrict__ lse_in) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TS = NT + 4, TT = NT / 16, PB = 4;
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int R = a.R, T = a.T, H = a.H, RR = R * R;
-    const Tile tl = skp_tile(a, blockIdx.y, tid);              // tile geometry (y0, seg, th_eff) + V-phase roles
-    float* Vt = smem;
-    int* tab_cy = (int*)(smem + a.vt_floats);
-    float* tab_wy = (float*)(tab_cy + a.TH * 4);
-
-    int prow[PB], px[PB], pp[PB];                               // this lane's pixel in each of its 4 blocks
-    bool pv[PB];
-#pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
-        const int lin = wave * 64 + pb * 16 + li;
-        if (R <= 256) { prow[pb] = lin / R; px[pb] = lin - prow[pb] * R; pv[pb] = prow[pb] < tl.th_eff; }
-        else { prow[pb] = 0; px[pb] = tl.seg * 256 + lin; pv[pb] = px[pb] < R; }
-        if (!pv[pb]) { prow[pb] = 0; px[pb] = (R <= 256) ? li : R - 16 + li; }
-        pp[pb] = (tl.y0 + prow[pb]) * R + px[pb];
-    }
-    f32x4 acc[PB][TT];
-#pragma unroll
-    for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[pb][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    int lh = 0;
-    for (int l = 0; l < a.L; ++l) {
-        const int s = a.s[l];
-        const float ratio = (float)s / (float)R;
-        float wB[PB][2];                                        // B operand: weight of column (cbu + 4*ks + g) for pixel px
-        int arow[PB][2];                                        // A operand: LDS float offset of that column's token row
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            int cx[4]; float wx[4];
-            skp_cubic_taps(px[pb], ratio, s, cx, wx);
-            const int ix = (int)floorf(ratio * ((float)px[pb] + 0.5f) - 0.5f);
-            const int cbu = (int)floorf(ratio * ((float)(px[pb] - li) + 0.5f) - 0.5f) - 1;   // block's first (unclamped) column
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int cv = cbu + 4 * ks + g;               // virtual column of this lane's k-slot
-                const int i = cv - (ix - 1);
-                wB[pb][ks] = (i == 0) ? wx[0] : (i == 1) ? wx[1] : (i == 2) ? wx[2] : (i == 3) ? wx[3] : 0.f;
-                const int cc = cv < 0 ? 0 : (cv > s - 1 ? s - 1 : cv);
-                arow[pb][ks] = (prow[pb] * s + cc) * TS + li;
-            }
-        }
-        __syncthreads();                                       // previous layer done with the tables
-        if (tid < tl.th_eff) {
-            int cy[4]; float wy[4];
-            skp_cubic_taps(tl.y0 + tid, ratio, s, cy, wy);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { tab_cy[tid * 4 + j] = cy[j]; tab_wy[tid * 4 + j] = wy[j]; }
-        }
-        const int rc = tl.th_eff * s;
-        for (int h = 0; h < H; ++h, ++lh) {
-            const float* Sg = a.S[l] + ((size_t)(b * H + h) * s * s) * a.ldt;
-            __syncthreads();                                   // tables ready / previous H phase done
-            skp_v_phase<NT>(Sg, Vt, tab_cy, tab_wy, s, rc, tid, a.ldt);
-            __syncthreads();
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                // operands first (independent LDS reads), then the two k-steps over all t-tiles (no dependent pairs
-                // back to back), accumulating from a shared zero vector (no per-tile zero fills)
-                float a0[TT], a1[TT];
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) { a0[tt] = Vt[arow[pb][0] + 16 * tt]; a1[tt] = Vt[arow[pb][1] + 16 * tt]; }
-                f32x4 sv[TT];
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) sv[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tt], wB[pb][0], zero4, 0, 0, 0);
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) sv[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tt], wB[pb][1], sv[tt], 0, 0, 0);
-                if (TT * 16 > T) {                              // pads live in the last t-tile only
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((TT - 1) * 16 + 4 * g + r >= T) sv[TT - 1][r] = -INFINITY;
-                }
-                const size_t lidx = ((size_t)b * a.L * H + lh) * RR + pp[pb];
-                if (MODE == 2) {
-                    const float lse = pv[pb] ? lse_in[lidx] : 0.f;
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) {
-                        const f32x4 e = sv[tt] - lse;
-                        acc[pb][tt] += f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]),
-                                             __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
-                    }
-                    continue;
-                }
-                float m = -INFINITY;
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt)
-                    m = fmaxf(m, fmaxf(fmaxf(sv[tt][0], sv[tt][1]), fmaxf(sv[tt][2], sv[tt][3])));
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {               // vector ops on f32x4 lower to v_pk_add/v_pk_fma pairs
-                    const f32x4 e = sv[tt] - m;
-                    sv[tt] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]),
-                                   __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
-                    s4 += sv[tt];
-                }
-                float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
-                if (MODE == 0) {
-                    const float inv = 1.0f / sum;
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) acc[pb][tt] = sv[tt] * inv + acc[pb][tt];
-                }
-                if (pv[pb] && g == 0) lse_out[lidx] = m + __builtin_amdgcn_logf(sum);
-            }
-        }
-    }
-    if (MODE != 1) {
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 16 * tt + 4 * g + r;
-                    if (pv[pb] && t < T) M[(size_t)b * a.m_bstride + (size_t)t * RR + pp[pb]] = acc[pb][tt][r] * a.inv_lh;
-                }
     }
 }
 
@@ -810,11 +512,7 @@ static int fill_args(MapArgs& a, const float* const* S, float* const* dS, const 
     a.L = L; a.B = B; a.H = H; a.T = T; a.smax = smax;
     a.vt_floats = a.TH * smax * (nt + 4);
     a.vt_floats = (a.vt_floats + 3) & ~3;
-    if (R <= 128) { a.TH2 = 128 / R; a.TW2 = R; a.segs2 = 1; }
-    else { a.TH2 = 1; a.TW2 = 128; a.segs2 = (R + 127) / 128; }
-    a.vt2_floats = (a.TH2 * smax * (nt + 4) + 3) & ~3;
     a.inv_lh = 1.0f / (float)(L * H);
-    { const char* e = getenv("SKP_MAP_QUAD"); if (e && e[0] == '0') for (int l = 0; l < L; ++l) a.quad[l] = 0; }   // A/B switch
     return 0;
 }
 
@@ -843,18 +541,9 @@ extern "C" int skp_attn_map_fwd_ex_f32(const float* const* S, const int* s, int 
     if ((mode != 1 && !M) || (mode != 2 && !lse_out) || (mode == 2 && !lse_in)) return SKP_E_BADARG;
     if (!n_tiles_ok(a)) return SKP_E_RANGE;
     a.ldt = ldt; a.m_bstride = m_bstride; a.mode = mode;
-    bool mfma = (R % 16) == 0;                                  // MFMA H phase: 16-pixel blocks, <= 8 columns per block
-    for (int l = 0; l < L; ++l) mfma = mfma && (4 * a.s[l] <= R);
-    // The MFMA H phase is correct but currently slower than the packed-VALU kernel (209 vs 161 us at the bench
-    // shape: un-pipelined operand reads, scalar softmax -- profiles/r01_map_fwd_variants.md); opt-in for A/B runs.
-    { const char* e = getenv("SKP_MAP_MFMA"); if (!(e && e[0] == '1')) mfma = false; }
-    // default: one lane per pixel (fastest measured); SKP_MAP_LANES=2 selects the two-lanes-per-pixel kernel
-    bool two = false;
-    { const char* e = getenv("SKP_MAP_LANES"); if (e && e[0] == '2' && !mfma) two = true; }
-    const int ntile = two ? (R <= 128 ? (R + a.TH2 - 1) / a.TH2 : R * a.segs2) : n_tiles(a);
+    const int ntile = n_tiles(a);
     if (ntile > 65535) return SKP_E_RANGE;
-    const size_t lds = two ? (4 * (size_t)a.vt2_floats + 8 * (size_t)a.TH2) * sizeof(float)
-                           : ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
+    const size_t lds = ((size_t)a.vt_floats + 8 * (size_t)a.TH) * sizeof(float);
     if (lds > 160 * 1024) return SKP_E_LDS;
     dim3 grid(B, ntile), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -867,10 +556,7 @@ extern "C" int skp_attn_map_fwd_ex_f32(const float* const* S, const int* s, int 
         }                                                                                                \
         hipLaunchKernelGGL((KERNEL<NTV, MD>), grid, block, lds, st, a, M, lse_out, lse_in);              \
     }
-#define SKP_FWD_M(NTV, MD)                                                                               \
-    if (mfma) SKP_FWD_K(skp_attn_map_fwd_mfma_kernel, NTV, MD)                                           \
-    else if (two) SKP_FWD_K(skp_attn_map_fwd2_kernel, NTV, MD)                                           \
-    else SKP_FWD_K(skp_attn_map_fwd_kernel, NTV, MD)
+#define SKP_FWD_M(NTV, MD) SKP_FWD_K(skp_attn_map_fwd_kernel, NTV, MD)
 #define SKP_FWD(NTV)                                                                                     \
     if (mode == 0) { SKP_FWD_M(NTV, 0) } else if (mode == 1) { SKP_FWD_M(NTV, 1) } else { SKP_FWD_M(NTV, 2) }
     SKP_NT_SWITCH(nt, SKP_FWD)

@@ -551,9 +551,8 @@ extern "C" int skp_attn_map_bwd_col_f32(const float* const* S, float* const* dS,
     // Route: the inline form everywhere it was measured (B = 8, R = 128, 16^2 x 3 + 32^2 layers: T = 77 344 -> 268 us, T = 128
     // 428 -> 394, T = 500 1 379 -> 1 217; 2 rows 213 -> 128; R = 256 746 -> 624).  With the row code instantiated twice (chunks
     // with / without a selected token) the sweep kernel needs 156 registers and no scratch (the two-sweep natural kernel: 240 + 12
-    // bytes).  SKP_MAP_COL_DOT=0 restores the two-sweep form (A/B).
-    static const bool inl = [] { const char* e = getenv("SKP_MAP_COL_DOT"); return !(e && e[0] == '0'); }();
-    if (inl) {     // dot by its own row-parallel kernel, then ONE sweep launch: natural chunks with their selected tokens inline
+    // bytes).
+    {              // dot by its own row-parallel kernel, then ONE sweep launch: natural chunks with their selected tokens inline
         int smax = 0;
         for (int l = 0; l < L; ++l) smax = s[l] > smax ? s[l] : smax;
         const dim3 dgrid((unsigned)((long)B * (R / CL_DR) * H * a.nl)), block(R);
@@ -568,18 +567,4 @@ extern "C" int skp_attn_map_bwd_col_f32(const float* const* S, float* const* dS,
         else hipLaunchKernelGGL((skp_map_bwd_col_kernel<256, false, true>), grid, block, lds, st, a);
         return skp_launch_status();
     }
-    for (int pass = 0; pass < 2; ++pass) {                      // 0: selected tokens (dot + their part), 1: natural chunks
-        a.nch = pass == 0 ? nsel : nt / CL_TC;
-        const dim3 grid((unsigned)((long)B * a.nch * H * a.nl)), block(R);
-        if (R == 128) {
-            if (pass == 0) hipLaunchKernelGGL((skp_map_bwd_col_kernel<128, true>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((skp_map_bwd_col_kernel<128, false>), grid, block, lds, st, a);
-        } else {
-            if (pass == 0) hipLaunchKernelGGL((skp_map_bwd_col_kernel<256, true>), grid, block, lds, st, a);
-            else hipLaunchKernelGGL((skp_map_bwd_col_kernel<256, false>), grid, block, lds, st, a);
-        }
-        int rc = skp_launch_status();
-        if (rc) return rc;
-    }
-    return 0;
 }

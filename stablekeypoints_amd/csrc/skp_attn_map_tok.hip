@@ -418,7 +418,7 @@ static int skp_tok_class(int s) { return s <= 8 ? 0 : (s <= 16 ? 1 : 2); }
 // bands of one launch (= the layers of one register class): the sweep is latency-bound per wave, so it wants every wave
 // slot of the chip filled and refilled (>= 6 waves per SIMD over the launch; measured), bands of >= 8 rows
 static int skp_tok_bands(const int* s, int L, int cls, int B, int H, int T, int R) {
-    { const char* e = getenv("SKP_MAP_BANDS"); if (e && atoi(e) > 0) return atoi(e) > R ? R : atoi(e); }
+    if (const int nb = skp_tune(SKP_TUNE_MAP_BANDS)) return nb > R ? R : nb;       // tests: force the band count
     int nl = 0;
     for (int l = 0; l < L; ++l) nl += skp_tok_class(s[l]) == cls;
     const long cols = (long)nl * B * ((H + 3) / 4) * ((T + 15) / 16);

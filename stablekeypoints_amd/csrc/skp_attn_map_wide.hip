@@ -190,9 +190,7 @@ static int wide_plan(const int* s, int L, int T, int R, WideArgs& a, WidePlan& p
     }
     // 64-token slices measured faster than 32 (1.84 vs 2.58 ms at T = 500); 32 only where 64 would leave most lanes idle
     int sw = T <= 192 ? 32 : 64;
-    { const char* e = getenv("SKP_MAP_SLICE"); if (e && atoi(e) == 64) sw = 64; if (e && atoi(e) == 32) sw = 32; }
-    int px = 32;                                               // 64-pixel tiles measured 4 % slower at T = 500 (opt-in)
-    { const char* e = getenv("SKP_MAP_TILE"); if (e && atoi(e) == 64 && R % 64 == 0) px = 64; }
+    int px = 32;                                               // (64-pixel tiles measured 4 % slower at T = 500)
     a.NS = (T + sw - 1) / sw;
     if (px * a.NS > 512) px = 32;                              // 512 threads: two waves per SIMD at 256 registers
     a.ncmax = (int)(((long)px * smax + R - 1) / R) + 4;

@@ -11,6 +11,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Developer overrides of launch plans (skp_tune_set in include/skp.h): tests and tools/ only, 0 = the library's own choice.
+// The library reads no environment variables.
+enum { SKP_TUNE_WINO_SPLIT = 0, SKP_TUNE_WINO_RAW_MAX_TILES, SKP_TUNE_MAP_BANDS, SKP_TUNE_FA2_TWO_KERNEL_BWD, SKP_TUNE_GN_FOLD_MAX_COUT,
+       SKP_TUNE_COUNT };
+int skp_tune(int key);                              // skp_select_loss.hip
+
 static inline int skp_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

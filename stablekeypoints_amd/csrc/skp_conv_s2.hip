@@ -198,8 +198,6 @@ __global__ __launch_bounds__(256) void skp_conv_s2_reduce_kernel(const float* __
 
 // K splits of a launch: enough workgroups for two per CU, at least four 16-channel stages each, at most eight
 static int s2_splits(int B, int Cin, int Cout, int H, int W) {
-    static const bool on = [] { const char* e = getenv("SKP_S2_SPLIT"); return !(e && e[0] == '0'); }();
-    if (!on) return 1;
     const long wgs = (long)B * ((H / 2) / S2_TOH) * ((W / 2) / S2_TOW) * ((Cout + 127) / 128);
     if (wgs >= 256) return 1;
     long s = (512 + wgs - 1) / wgs;

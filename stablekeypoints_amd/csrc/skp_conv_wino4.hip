@@ -891,9 +891,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
 // rows, guarded stores): the 320-channel UNet layers run 3 groups (17 % idle MFMA rows) and still gain from the form's
 // shorter stages (one patch per thread instead of two).
 static bool wino4_use_c128(int Cout, int tiles) {
-    if (const char* e = getenv("SKP_WINO_C128")) { if (e[0] == '0') return (Cout % 128 == 0) && tiles >= 256; }
-    static const int min_tiles = [] { const char* e = getenv("SKP_WINO_C128_MIN_TILES"); return e ? atoi(e) : 128; }();
-    return tiles >= min_tiles && (Cout % 128 == 0 || (Cout > 128 && Cout % 128 >= 64));
+    return tiles >= 128 && (Cout % 128 == 0 || (Cout > 128 && Cout % 128 >= 64));
 }
 
 // Workgroup grid of a launch with S K-splits (the order is explained at w4_work) and the number of waves of workgroups it
@@ -924,8 +922,7 @@ int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     const bool c128 = wino4_use_c128(Cout, tiles);
     const int nsteps = Cin / 16;
     const double out_bytes = (double)B * Cout * H * W * 4;
-    if (const char* e = getenv("SKP_WINO_SPLIT")) {              // experiments: force the K split
-        const int S = atoi(e);
+    if (const int S = skp_tune(SKP_TUNE_WINO_SPLIT)) {           // tests / tools: force the K split
         if (S >= 1 && S <= 16 && (S - 1) * ((nsteps + S - 1) / S) < nsteps) return S;
     }
     int best = 1;
@@ -933,11 +930,9 @@ int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     // measured stage times (us): the 128-channel form ~3.9, the 64-channel form ~5.6 (tools/conv_bench.py with SKP_WINO_SPLIT
     // forced); the reduce pass streams (S + 1) x the output at ~8 TB/s (the partials are L2 / MALL resident)
     const double stage_us = c128 ? 3.9 : 5.6;
-    static const bool ragged = [] { const char* e = getenv("SKP_WINO_RAGGED"); return !(e && e[0] == '0'); }();
     for (int S = 1; S <= 16; ++S) {
         const int per = (nsteps + S - 1) / S;
         if ((S - 1) * per >= nsteps) continue;                   // an empty last split
-        if (!ragged && nsteps % S) continue;
         const Wino4Grid g = wino4_grid(Cout, tiles, S);
         double cost = g.rounds * (per + 2.0) * stage_us;       // ~2 stages of prologue + epilogue per workgroup
         if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
@@ -966,11 +961,8 @@ static Wino4Grid wino4r_grid(int Cout, int tiles, int S) {
 // (the UNet's 8^2 / 16^2 levels and 1280 -> 1280 at 32^2, measured at 4 .. 40 rows: -12 .. -26 %), and up to 512 tiles when one
 // side has >= 1920 channels (the 32^2 skip-connection layers: -7 %); the 640-channel layers stay on the transformed-filter
 // kernels (equal or faster there at the step's 8 rows).
-// SKP_WINO_RAW_MAX_TILES=<n>: every qualifying shape up to n tiles (experiments).
-static int wino4r_max_tiles() {
-    static const int v = [] { const char* e = getenv("SKP_WINO_RAW_MAX_TILES"); return e ? atoi(e) : 0; }();
-    return v;
-}
+// skp_tune_set("wino_raw_max_tiles", n): every qualifying shape up to n tiles (tools/conv_raw_bench.py).
+static int wino4r_max_tiles() { return skp_tune(SKP_TUNE_WINO_RAW_MAX_TILES); }
 static bool wino4r_layout_ok(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
     if ((Cin % 16) || (Cout % 64) || (H % 4) || (W % 4)) return false;
@@ -989,8 +981,7 @@ static int wino4r_plan(int B, int Cin, int Cout, int H, int W) {
     const int tiles = B * (H / 4) * (W / 4);
     const int nsteps = Cin / 16;
     const double out_bytes = (double)B * Cout * H * W * 4;
-    if (const char* e = getenv("SKP_WINO_SPLIT")) {
-        const int S = atoi(e);
+    if (const int S = skp_tune(SKP_TUNE_WINO_SPLIT)) {
         if (S >= 1 && S <= 16 && (S - 1) * ((nsteps + S - 1) / S) < nsteps) return S;
     }
     int best = 1;
@@ -1040,11 +1031,11 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
 // channel group redoes the SiLU of its input patches; since the accumulators are named (no spills in the folded kernel) that
 // costs less than the separate GroupNorm apply pass (one read + one write of the activation) up to the VAE's 512-channel levels:
 // 256 -> 256 @256^2 1 794 -> 1 657 us, 512 -> 512 @128^2 1 580 -> 1 493, 512 -> 512 @64^2 436 -> 401 (tools/gn_fold_bench.py;
-// rounds 3-4 gated at ONE group: profiles/r03_conv_gn_fold.md).  SKP_GN_FOLD_MAX_COUT=<n>: A/B runs.
+// rounds 3-4 gated at ONE group: profiles/r03_conv_gn_fold.md).  skp_tune_set("gn_fold_max_cout", n): A/B runs.
 extern "C" int skp_conv3x3_f4_gn_ok(int B, int Cin, int Cout, int H, int W) {
     if (wino4_plan(B, Cin, Cout, H, W) != 1) return 0;
     const int tiles = B * (H / 4) * (W / 4);
-    static const int max_cout = [] { const char* e = getenv("SKP_GN_FOLD_MAX_COUT"); return e ? atoi(e) : 512; }();
+    const int max_cout = skp_tune(SKP_TUNE_GN_FOLD_MAX_COUT) ? skp_tune(SKP_TUNE_GN_FOLD_MAX_COUT) : 512;
     return (wino4_use_c128(Cout, tiles) && Cout <= max_cout) ? 1 : 0;
 }
 
@@ -1121,8 +1112,7 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
     a.gx = (int)g.gx;
     a.vtotal = g.tb_per_xcd ? (int)g.gx * S : (int)g.gx;
     // 128-channel form: persistent workgroups, one per CU (the ids are multiples of 8 apart, so a workgroup stays on its XCD's band)
-    static const int persist = [] {                 // SKP_WINO_PERSIST=0: one workgroup per unit; unset: one per CU of this device
-        if (const char* e = getenv("SKP_WINO_PERSIST")) return atoi(e);
+    static const int persist = [] {                 // one workgroup per CU of this device
         int dev = 0, ncu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = 256;
         return ncu;
@@ -1153,8 +1143,7 @@ static int wino4_run(const void* x, const void* U, const void* bias, const void*
 // Raw-filter form (small-spatial layers): see skp_wino4r_conv_kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int skp_conv3x3_f4r_ok(int B, int Cin, int Cout, int H, int W) {
-    static const bool on = [] { const char* e = getenv("SKP_WINO_RAW"); return !(e && e[0] == '0'); }();
-    return (on && wino4r_shape_ok(B, Cin, Cout, H, W)) ? 1 : 0;
+    return wino4r_shape_ok(B, Cin, Cout, H, W) ? 1 : 0;
 }
 
 // R: 9 * Cin * Cout floats.  flip_transpose as skp_conv3x3_f4_filter_f32 (the backward-data filter of w[Cin][Cout][3][3]).

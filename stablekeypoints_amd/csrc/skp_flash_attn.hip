@@ -987,10 +987,6 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
                 int Nk, int d, float scale, void* stream) {
     const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
-    const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
-    const int variant = ev ? atoi(ev) : 0;
-    const char* eo = getenv("SKP_FA2_OPT");
-    const int opt = eo ? atoi(eo) : 6;
 #define FA2_FWD(DV, NQ, W, O) return fa2_launch_fwd<DV, NQ, W, O>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st)
     // OPT bits: 2 = row sums through the idle MFMA rows (D % 16 != 0), 4 = precomputed staging offsets.  Measured
     // (profiles/r02_flash_attn.md): 64 queries per wave wins where the grid still fills the chip twice; the precomputed
@@ -998,21 +994,14 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
     const bool big = (long)((N + 255) / 256) * H * B >= 512;
     switch (d) {
         case 40:
-            if (variant == 1 || (variant == 0 && !big)) { if (opt == 0) FA2_FWD(40, 2, 2, 0); if (opt == 4) FA2_FWD(40, 2, 2, 4); FA2_FWD(40, 2, 2, 6); }
-            if (opt == 0) FA2_FWD(40, 4, 2, 0);
-            if (opt == 4) FA2_FWD(40, 4, 2, 4);
+            if (!big) FA2_FWD(40, 2, 2, 6);
             FA2_FWD(40, 4, 2, 6);
-        case 64:                                                // (64 queries per wave spills at this head size)
-            if (opt == 0) FA2_FWD(64, 2, 2, 0);
-            FA2_FWD(64, 2, 2, 4);
-        case 80:
-            if (opt == 4) FA2_FWD(80, 2, 2, 4);
-            FA2_FWD(80, 2, 2, 0);
+        case 64: FA2_FWD(64, 2, 2, 4);                          // (64 queries per wave spills at this head size)
+        case 80: FA2_FWD(80, 2, 2, 0);
         case 160:                                               // 16^2 layers (N = 256): 16 queries per wave, 32-key tiles
-            // few workgroups, short key axis: the key tiles split over two wave sets of one workgroup (variant 3: the one-set kernel)
-            if (variant != 3 && variant != 4 && Nk >= 4 * FA2<160>::KT && (long)((N + 63) / 64) * H * B <= 1024)
+            // few workgroups, short key axis: the key tiles split over two wave sets of one workgroup
+            if (Nk >= 4 * FA2<160>::KT && (long)((N + 63) / 64) * H * B <= 1024)
                 return fa2_launch_fwd_halves<160>(q, k, v, out, lse, B, H, N, Nk, kvb, scale, st);
-            if (variant == 4) FA2_FWD(160, 1, 1, 0);
             FA2_FWD(160, 1, 1, 4);
         default: return -100;
     }
@@ -1044,8 +1033,7 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
 }
 
 static bool fa2_fused_ok(int Bk, int B, int H, int N, int Nk, int d) {
-    const char* e = getenv("SKP_FA2_FUSED");                     // A/B switch: 0 = the two-kernel backward
-    if (e && e[0] == '0') return false;
+    if (skp_tune(SKP_TUNE_FA2_TWO_KERNEL_BWD)) return false;     // tests: the two-kernel backward at the fused form's shapes
     // 40-wide heads: two workgroups per CU (79 KB LDS, 254 registers); 64-wide: two per CU with the dS exchange laid over the
     // Q | dO tiles and the K fragments read from LDS (70 KB, 256 registers): 0.58 -> 0.75 of peak; 80-wide: 64-query tiles on
     // eight waves (round 3): 0.42 (two kernels) -> 0.53 (48-query four-wave form, round 2) -> 0.59 at N = 1024, 0.72 at N = 4096.
@@ -1098,37 +1086,20 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
                 int allow_fused, int ldg, void* stream) {
     const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
-    const char* ev = getenv("SKP_FA2_VARIANT");                 // tile-shape A/B switch (tools/fa_bench.py)
-    const int variant = ev ? atoi(ev) : 0;
     if (allow_fused && fa2_fused_ok(Bk, B, H, N, Nk, d)) {
         if (d == 40) return fa2_launch_bwd_fused<40, 2, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
         if (d == 64) return fa2_launch_bwd_fused<64, 2, true, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
         // 80-wide heads: 64-query tiles on EIGHT waves (16 keys each: half the K / V fragments and dK / dV accumulators per wave,
-        // 224 registers, nothing spilled, two waves per SIMD at one 120 KB workgroup per CU).  SKP_FA2_D80=3: the 48-query
-        // four-wave form of round 2 (two workgroups per CU, 57 spilled registers), =1: 64 queries on four waves (one per SIMD)
-        { const char* e8 = getenv("SKP_FA2_D80");
-          if (e8 && e8[0] == '1') return fa2_launch_bwd_fused<80, 1, false, 4>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
-          if (e8 && e8[0] == '3') return fa2_launch_bwd_fused<80, 2, true, 3>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st); }
+        // 224 registers, nothing spilled, two waves per SIMD at one 120 KB workgroup per CU)
         return fa2_launch_bwd_fused<80, 1, false, 4, 8>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, scale, ldg, st);
     }
 #define FA2_BWD(DV, NQ, WQ, NT, WT, PRE) \
     return fa2_launch_bwd<DV, NQ, WQ, NT, WT, PRE>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, Nk, kvb, scale, ldg, st)
     switch (d) {
-        case 40:
-            if (variant == 1) FA2_BWD(40, 1, 3, 1, 3, true);
-            if (variant == 2) FA2_BWD(40, 2, 2, 2, 2, false);
-            FA2_BWD(40, 2, 2, 2, 2, true);
-        case 64:
-            if (variant == 1) FA2_BWD(64, 2, 2, 2, 1, true);
-            if (variant == 2) FA2_BWD(64, 2, 2, 1, 2, false);
-            FA2_BWD(64, 2, 2, 1, 2, true);
-        case 80:                                                // one wave per SIMD, 32 rows per wave (measured best)
-            if (variant == 1) FA2_BWD(80, 1, 2, 1, 2, false);
-            if (variant == 2) FA2_BWD(80, 2, 1, 2, 1, true);
-            FA2_BWD(80, 2, 1, 2, 1, false);
-        case 160:
-            if (variant == 4) FA2_BWD(160, 1, 1, 1, 1, false);
-            FA2_BWD(160, 1, 1, 1, 1, true);
+        case 40: FA2_BWD(40, 2, 2, 2, 2, true);
+        case 64: FA2_BWD(64, 2, 2, 1, 2, true);
+        case 80: FA2_BWD(80, 2, 1, 2, 1, false);                // one wave per SIMD, 32 rows per wave (measured best)
+        case 160: FA2_BWD(160, 1, 1, 1, 1, true);
         default: return -100;
     }
 #undef FA2_BWD

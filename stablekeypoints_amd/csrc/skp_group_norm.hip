@@ -346,10 +346,8 @@ __global__ __launch_bounds__(1024) void skp_gn_onepass_bwd_kernel(GNArgs a, cons
     }
 }
 
-// float4 per thread the one-pass forms would need for this row length; 0 = not served (SKP_GN_ONEPASS=0 switches them off)
+// float4 per thread the one-pass forms would need for this row length; 0 = not served
 static int gn_onepass_vpt(const GNArgs& a, bool backward) {
-    static const bool on = [] { const char* e = getenv("SKP_GN_ONEPASS"); return !(e && e[0] == '0'); }();
-    if (!on) return 0;
     const long q4 = a.L / 4, need = (q4 + 1023) / 1024;
     // (the forward at 8 float4 per thread is left out: this compiler spills it -- 128 registers + 408 bytes of scratch -- while
     // 10 and 16 compile clean at 86 / 122; the backward holds two arrays and stops at 10 = 112 registers)
@@ -409,6 +407,15 @@ extern "C" int skp_group_norm_nsplit(int N, int C, int G, int HW) {
     static const float dummy = 0.f;
     int rc = gn_fill(a, &dummy, nullptr, &dummy, &dummy, N, C, G, HW, 1e-5f, 0);
     return rc ? rc : a.nsplit;
+}
+
+// 1 when the forward of this shape holds its (sample, group) rows in registers (one launch, exact statistics from the loaded row):
+// callers use it to decide whether a producing convolution should leave block statistics behind at all.
+extern "C" int skp_group_norm_onepass_ok(int N, int C, int G, int HW) {
+    if (N <= 0 || C <= 0 || G <= 0 || HW <= 0 || C % G || (HW & 3)) return 0;
+    GNArgs a{};
+    a.N = N; a.C = C; a.G = G; a.HW = HW; a.L = (long)(C / G) * HW;
+    return gn_onepass_vpt(a, false) ? 1 : 0;
 }
 
 extern "C" int skp_group_norm_fwd_f32(const float* x, const float* off, const float* gamma, const float* beta,

@@ -3,6 +3,7 @@
 // single-workgroup selection that replaces ~500 tiny launches and .item() syncs of the reference
 // (ptp_utils.py:115-159).
 #include "skp_common.h"
+#include <string.h>
 
 // (value desc, index asc) ordering == torch.argmax "first maximal index".
 __device__ __forceinline__ bool skp_better(float v, int i, float bv, int bi) {
@@ -407,4 +408,21 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 35; }
+extern "C" int skp_abi_version(void) { return 36; }
+
+// ---- developer overrides (include/skp.h: skp_tune_set) ----
+static int g_tune[SKP_TUNE_COUNT] = {0};
+static const char* const g_tune_names[SKP_TUNE_COUNT] = {"wino_split", "wino_raw_max_tiles", "map_bands", "fa2_two_kernel_bwd", "gn_fold_max_cout"};
+int skp_tune(int key) { return (key >= 0 && key < SKP_TUNE_COUNT) ? g_tune[key] : 0; }
+extern "C" int skp_tune_set(const char* key, int value) {
+    if (!key || value < 0) return SKP_E_BADARG;
+    for (int i = 0; i < SKP_TUNE_COUNT; ++i)
+        if (!strcmp(key, g_tune_names[i])) { g_tune[i] = value; return 0; }
+    return SKP_E_RANGE;
+}
+extern "C" int skp_tune_get(const char* key) {
+    if (!key) return SKP_E_BADARG;
+    for (int i = 0; i < SKP_TUNE_COUNT; ++i)
+        if (!strcmp(key, g_tune_names[i])) return g_tune[i];
+    return SKP_E_RANGE;
+}

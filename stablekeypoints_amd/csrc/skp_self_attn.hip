@@ -255,20 +255,13 @@ int skp_fa2_bwd(const float* q, const float* k, const float* v, const float* out
 
 int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d);
 
-static bool sa_gen1() {                                         // SKP_FLASH_GEN=1 forces the first-generation kernels (A/B runs)
-    const char* e = getenv("SKP_FLASH_GEN");
-    return e && e[0] == '1';
-}
-
 extern "C" int skp_flash_attn_fwd_f32(const float* q, const float* k, const float* v, float* out, float* lse,
                                       int B, int Bk, int H, int N, int Nk, int d, float scale, void* stream) {
     if (!q || !k || !v || !out || !lse) return SKP_E_BADARG;
     int rc = sa_check(B, Bk, H, N, Nk, d);
     if (rc) return rc;
-    if (!sa_gen1()) {
-        rc = skp_fa2_fwd(q, k, v, out, lse, B, Bk, H, N, Nk, d, scale, stream);
-        if (rc != -100) return rc;
-    }
+    rc = skp_fa2_fwd(q, k, v, out, lse, B, Bk, H, N, Nk, d, scale, stream);      // head sizes 40 / 64 / 80 / 160
+    if (rc != -100) return rc;
     const int kvb = Bk == 1 ? 0 : 1;
     dim3 grid((N + 127) / 128, H, B), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -276,17 +269,14 @@ extern "C" int skp_flash_attn_fwd_f32(const float* q, const float* k, const floa
         case 8: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 1, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
         case 16: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 2, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
         case 32: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 4, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
-        case 40: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 5, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
-        case 64: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 8, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
-        case 80: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 10, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
-        default: SKP_SA_LAUNCH(skp_self_attn_fwd_kernel, 20, 2, 2, 0, q, k, v, out, lse, H, N, Nk, kvb, scale) break;
+        default: return SKP_E_RANGE;
     }
     return skp_launch_status();
 }
 
 extern "C" int64_t skp_flash_attn_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     if (B <= 0 || H <= 0 || N <= 0 || Nk <= 0 || d <= 0 || (Bk != 1 && Bk != B)) return SKP_E_BADARG;
-    if (sa_gen1()) return (int64_t)B * H * N * (int64_t)sizeof(float);
+    if (d < 40) return (int64_t)B * H * N * (int64_t)sizeof(float);      // first-generation kernels (8 / 16 / 32-wide heads)
     return skp_fa2_bwd_workspace(B, Bk, H, N, Nk, d);
 }
 
@@ -319,10 +309,8 @@ static int flash_bwd_impl(const float* q, const float* k, const float* v, const 
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return SKP_E_BADARG;
     int rc = sa_check(B, Bk, H, N, Nk, d);
     if (rc) return rc;
-    if (!sa_gen1()) {
-        rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, allow_fused, ldg, stream);
-        if (rc != -100) return rc;
-    }
+    rc = skp_fa2_bwd(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, Bk, H, N, Nk, d, scale, allow_fused, ldg, stream);
+    if (rc != -100) return rc;
     if (ldg != H * d) return SKP_E_RANGE;                        // the first-generation kernels write dense rows only
     const int kvb = Bk == 1 ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
@@ -332,10 +320,7 @@ static int flash_bwd_impl(const float* q, const float* k, const float* v, const 
             case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 1, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
             case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 2, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
             case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 4, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
-            case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 5, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
-            case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 8, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
-            case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 10, 2, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
-            default: SKP_SA_LAUNCH(skp_self_attn_bwd_dq_kernel, 20, 1, 2, 0, q, k, v, out, dout, lse, dq, workspace, H, N, Nk, kvb, scale) break;
+        default: return SKP_E_RANGE;
         }
     }
     rc = skp_launch_status();
@@ -345,10 +330,7 @@ static int flash_bwd_impl(const float* q, const float* k, const float* v, const 
         case 8: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 1, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
         case 16: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 2, 2, 2, 128, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
         case 32: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 4, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
-        case 40: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 5, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
-        case 64: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 8, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
-        case 80: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 10, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
-        default: SKP_SA_LAUNCH(skp_self_attn_bwd_dkv_kernel, 20, 1, 2, 64, q, k, v, dout, lse, workspace, dk, dv, H, N, Nk, kvb, scale) break;
+        default: return SKP_E_RANGE;
     }
     return skp_launch_status();
 }

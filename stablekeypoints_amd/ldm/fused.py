@@ -123,10 +123,10 @@ def _transformer_forward(m: Transformer2DModel):
         # token layout throughout: the 1x1 convolutions are nn.Linear over tokens (bias fused in the GEMM), the two
         # permutes are tiled transposes and the residual add rides on the way back
         t = ops.nchw_to_tokens(h)
-        t = ops.linear_auto(t, m.proj_in.weight.flatten(1), m.proj_in.bias)
+        t = F.linear(t, m.proj_in.weight.flatten(1), m.proj_in.bias)
         for blk in m.transformer_blocks:
             t = blk(t, context=context)
-        t = ops.linear_auto(t, m.proj_out.weight.flatten(1), m.proj_out.bias)
+        t = F.linear(t, m.proj_out.weight.flatten(1), m.proj_out.bias)
         return ops.tokens_to_nchw_add(t, x)
     return forward
 
@@ -190,20 +190,11 @@ def _downsample_forward(m):
     return forward
 
 
-def _linear_forward(m: torch.nn.Linear):
-    def forward(x):
-        return ops.linear_auto(x, m.weight, m.bias)
-    return forward
-
-
 def fuse_norms(module: torch.nn.Module) -> int:
     n = 0
     for mod in module.modules():
         if isinstance(mod, UNet2DConditionModel) and "time_path" not in mod.__dict__:
             mod.time_path = _time_path(mod)
-            continue
-        if ops.EMULATED_F32 and isinstance(mod, torch.nn.Linear) and "forward" not in mod.__dict__:
-            mod.forward = _linear_forward(mod)      # experiment: frozen Linear layers on the split-bf16 GEMM
             continue
         if isinstance(mod, Downsample2D) and "forward" not in mod.__dict__:
             mod.forward = _downsample_forward(mod); n += 1

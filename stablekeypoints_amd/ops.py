@@ -6,7 +6,6 @@ stream.  No op has an eager/CPU fallback: a non-CUDA tensor raises.
 """
 from __future__ import annotations
 
-import os
 from typing import List, Sequence, Tuple
 
 import torch
@@ -63,7 +62,7 @@ def _log2sumexp2(xs: List[torch.Tensor]) -> torch.Tensor:
     return m + torch.log2(torch.exp2(st - m).sum(dim=0))
 
 
-MAP_WIDE = os.environ.get("SKP_MAP_WIDE", "1") != "0"          # A/B switch: "0" = token groups x two passes for T > 128
+MAP_WIDE = True          # False (tests): token groups x two passes for T > 128
 MAP_WIDE_MAX_T = 1024
 
 
@@ -156,9 +155,9 @@ def _map_bwd(S, dS, sides, B, H, T, R, dM, lse):
 #   other shapes: T <= 128 the dense-gradient kernels (the token-major sweep is slower there: 636 us), T > 128 the
 #   token-major sweep (2.4 vs 7.9 ms at T = 500, B = 8, for token groups x two passes of the dense kernels).
 # "col" / "sweep" force one sparse kernel where it serves the shapes, "sparse" = either, "dense" forces the dense route.
-MAP_BWD_MODE = os.environ.get("SKP_MAP_BWD", "auto")
+MAP_BWD_MODE = "auto"
 MAP_SPARSE_MAX_SIDE, MAP_SPARSE_MAX_K, MAP_SPARSE_MAX_R = 32, 32, 1024     # limits of csrc/skp_attn_map_tok.hip
-COL_MAX_T = int(os.environ.get("SKP_MAP_COL_MAX_T", "1024"))                 # token counts the column sweep is taken for (A/B: 128)
+COL_MAX_T = 1024                                                             # token counts the column sweep is taken for
 
 
 def map_bwd_col_supported(sides, K: int, R: int, T: int, heads: int = 8) -> bool:
@@ -414,7 +413,7 @@ def fused_losses(M, Mt, sel, argmax, theta, sigma: float, num_subjects: int = 1)
     return LossesFn.apply(M, Mt, sel, argmax, invert_affine(theta), float(sigma), int(num_subjects))
 
 
-MAP_LOSSES_BATCHED = os.environ.get("SKP_MAP_LOSSES_BATCHED", "1") != "0"     # A/B switch: statistics / selection per image
+MAP_LOSSES_BATCHED = True     # False (tests): statistics / selection per image, through meta["score_fn"]
 
 
 class MapLossesFn(torch.autograd.Function):
@@ -668,8 +667,8 @@ class GroupNormSiLUForkFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
-GN_FUSED_STATS = os.environ.get("SKP_GN_FUSED_STATS", "1") != "0"
-GN_FORK = os.environ.get("SKP_GN_FORK", "1") != "0"            # A/B switch
+GN_FUSED_STATS = True
+GN_FORK = True
 
 
 def group_norm_silu(x, norm: torch.nn.GroupNorm, off=None, silu: bool = True):
@@ -704,7 +703,7 @@ def self_attn_supported(C: int, heads: int) -> bool:
 # EXPERIMENT (opt-in, never the path of record): the flash-attention FORWARD on the bf16 matrix cores with three-term operand
 # splits (csrc/skp_flash_attn_s.hip; same out / lse contract, the fp32 backward kernels run on its lse).  SKP_FLASH_SPLIT=1
 # routes the layers it serves (d = 40 / 80, >= 1024 keys) through it; bench.py reports that step as `f32_split`.
-FLASH_SPLIT = os.environ.get("SKP_FLASH_SPLIT", "0") == "1"
+FLASH_SPLIT = False
 FLASH_SPLIT_MIN_KEYS = 1024
 
 
@@ -824,7 +823,7 @@ def add_bias_residual(a, b, bias):
 # ---------------------------------------------------------------------------------------------------------
 # residual add + LayerNorm of the transformer blocks, one pass per direction (csrc/skp_layer_norm.hip)
 # ---------------------------------------------------------------------------------------------------------
-ADD_LN = os.environ.get("SKP_ADD_LN", "1") != "0"                # A/B switch
+ADD_LN = True
 
 
 def add_layer_norm_supported(h, norm: torch.nn.LayerNorm) -> bool:
@@ -960,46 +959,6 @@ def _conv3x3_f4_raw(x, U, bias, cout, split=True, residual=None, out=None, stats
     return y
 
 
-def _wino4s_filters(weight, backward):
-    """Three bf16 planes of the F(4x4,3x3) transformed filter of a frozen weight (36*Cin*Cout*3 bf16), built once and kept
-    resident (csrc/skp_conv_wino4s.hip: the split form)."""
-    key = "_skp_wino4s_bwd" if backward else "_skp_wino4s_fwd"
-    hit = getattr(weight, key, None)
-    tag = (weight._version, weight.data_ptr())
-    if hit is not None and hit[0] == tag and hit[1].device == weight.device:
-        return hit[1]
-    w = _dev(weight.detach(), "weight")
-    co, ci = w.shape[:2]
-    Us = torch.empty(36 * co * ci * 3, device=w.device, dtype=torch.int16)
-    if backward:
-        N.check(N.lib().skp_conv3x3_f4s_filter_f32(w.data_ptr(), Us.data_ptr(), ci, co, 1, _stream()), "skp_conv3x3_f4s_filter_f32")
-    else:
-        N.check(N.lib().skp_conv3x3_f4s_filter_f32(w.data_ptr(), Us.data_ptr(), co, ci, 0, _stream()), "skp_conv3x3_f4s_filter_f32")
-    setattr(weight, key, (tag, Us))
-    return Us
-
-
-def _conv3x3_f4s_raw(x, Us, bias, cout, split=True, residual=None, out=None, stats=None):
-    """y = conv3x3(x) on the bf16 matrix cores with three-term operand splits (fp32 in / out / accumulate)."""
-    B, ci, H, W = x.shape
-    y = out if out is not None else torch.empty(B, cout, H, W, device=x.device, dtype=torch.float32)
-    nbytes = N.lib().skp_conv3x3_f4s_workspace(B, ci, cout, H, W) if (split and stats is None) else 0
-    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
-    N.check(N.lib().skp_conv3x3_f4s_f32(x.data_ptr(), Us.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                        residual.data_ptr() if residual is not None else None, y.data_ptr(),
-                                        ws.data_ptr() if ws is not None else None, stats.data_ptr() if stats is not None else None,
-                                        B, ci, cout, H, W, _stream()), "skp_conv3x3_f4s_f32")
-    return y
-
-
-def conv3x3_f4s(x, weight, bias=None, residual=None, backward=False):
-    """Direct entry to the split form (tests / tools): forward conv3x3 of `weight` [Cout,Cin,3,3], or with `backward` the
-    input-gradient convolution (x = dy [B,Cout,H,W] -> [B,Cin,H,W])."""
-    x = _dev(x, "x")
-    cout = weight.shape[1] if backward else weight.shape[0]
-    return _conv3x3_f4s_raw(x, _wino4s_filters(weight, backward), bias, int(cout), residual=residual)
-
-
 def _wino4r_filters(weight, backward):
     """The 9 taps of a frozen weight in MFMA operand order for the raw-filter form (9*Cin*Cout floats), built once."""
     key = "_skp_wino4r_bwd" if backward else "_skp_wino4r_fwd"
@@ -1037,7 +996,7 @@ def conv3x3_f4r_ok(x_shape, cout) -> bool:
 
 # "f4": Winograd F(4x4,3x3) where the shape allows (H, W % 4 == 0), F(2x2,3x3) otherwise; "f2": F(2x2,3x3) only;
 # "lib": library convolution everywhere (A/B runs and the consistency test).  Default f4.
-CONV3X3_MODE = os.environ.get("SKP_CONV3X3", "f4")
+CONV3X3_MODE = "f4"
 
 
 def conv3x3_f4_ok(x_shape, w_shape):
@@ -1126,14 +1085,13 @@ def conv3x3(x, weight, bias=None, residual=None):
     return Conv3x3Fn.apply(x, weight, bias, residual)
 
 
-GN_ONEPASS = os.environ.get("SKP_GN_ONEPASS", "1") != "0"      # mirrors the switch the library reads (csrc/skp_group_norm.hip)
-GN_ONEPASS_MAX_ROW = 16 * 1024 * 4                               # elements per (sample, group) row the one-pass forward holds
+GN_ONEPASS = True        # False (tests): producers leave block statistics behind even where the norm would not want them
 
 
-def _stats_useful(cout: int, h: int, w: int, groups: int = 32) -> bool:
+def _stats_useful(cout: int, h: int, w: int, groups: int = 32, rows: int = 1) -> bool:
     """Block statistics in a convolution's epilogue only pay where the GroupNorm that follows does not hold its rows in
-    registers anyway (the one-pass form computes exact statistics from the row it has loaded)."""
-    return not (GN_ONEPASS and cout % groups == 0 and (cout // groups) * h * w <= GN_ONEPASS_MAX_ROW)
+    registers anyway (the one-pass form computes exact statistics from the row it has loaded; the library says which)."""
+    return not (GN_ONEPASS and cout % groups == 0 and N.lib().skp_group_norm_onepass_ok(int(rows), int(cout), int(groups), int(h * w)))
 
 
 def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
@@ -1161,7 +1119,7 @@ def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
 
 # GroupNorm(+offset)+SiLU folded into the consuming Winograd convolution (forward only, single output-channel group):
 # saves the norm's apply pass (one read + one write of the activation); SKP_GN_FOLD=0 for A/B runs.
-GN_FOLD = os.environ.get("SKP_GN_FOLD", "1") != "0"
+GN_FOLD = True
 
 
 def conv3x3_gn_fold_ok(x, norm: torch.nn.GroupNorm, weight, *others) -> bool:
@@ -1253,89 +1211,6 @@ def mfma_issue_rate(waves_per_simd: int = 1, iters: int = 20000, device=None) ->
     return float(out.value)
 
 
-# ---------------------------------------------------------------------------------------------------------
-# EXPERIMENT (SKP_EMULATED_F32=1, separate bench line): frozen nn.Linear layers on the bf16 matrix cores with three-term
-# operand splits and six fp32-accumulated products (tools/csrc/skp_gemm_x3.hip).  Off by default: fp32 MFMA / library GEMMs.
-# ---------------------------------------------------------------------------------------------------------
-EMULATED_F32 = os.environ.get("SKP_EMULATED_F32", "0") == "1"
-
-
-_X3_CACHE = {}
-
-
-def _x3_planes(weight, transpose: bool):
-    """bf16 (h, m, l) planes of a frozen [N, K] weight ([3][N][K]) or of its transpose ([3][K][N]).  Cached per storage
-    address + shape (call sites pass fresh views such as `conv.weight.flatten(1)`), re-made when the version moves."""
-    import weakref
-    owner = weight._base if weight._base is not None else weight          # the Parameter behind a view such as .flatten(1)
-    key = (weight.data_ptr(), tuple(weight.shape), weight.device, bool(transpose))
-    hit = _X3_CACHE.get(key)
-    # the entry is only valid for the tensor it was made from: a freed model's address can be handed to another weight
-    if hit is not None and hit[0] == weight._version and hit[2]() is owner:
-        return hit[1]
-    w = _dev(weight.detach(), "weight")
-    n, k = w.shape
-    rows, cols = (k, n) if transpose else (n, k)
-    planes = torch.empty(3 * rows * cols, device=w.device, dtype=torch.bfloat16)
-    N.check(N.lab().skp_gemm_x3_split_f32(w.data_ptr(), planes.data_ptr(), rows, cols, int(transpose), _stream()),
-            "skp_gemm_x3_split_f32")
-    _X3_CACHE[key] = (weight._version, planes, weakref.ref(owner))
-    return planes
-
-
-X3_MIN_WIDTH = 2048     # output width from which the split kernel beats the library GEMM (profiles/r02_gemm_x3.md)
-
-
-def linear_x3_supported(x, weight) -> bool:
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 2 and not weight.requires_grad
-            and weight.shape[0] % 32 == 0 and weight.shape[1] % 32 == 0 and x.shape[-1] == weight.shape[1])
-
-
-def linear_x3_wanted(x, weight) -> bool:
-    """Measured: the 128 x 128-tile kernel wins (1.1-1.3x) where the output is wide (GEGLU projections) and many rows
-    amortise its operand traffic; narrow outputs and short row counts stay on the library."""
-    rows = x.numel() // x.shape[-1]
-    return linear_x3_supported(x, weight) and weight.shape[0] >= X3_MIN_WIDTH and rows >= 2048
-
-
-class LinearX3Fn(torch.autograd.Function):
-    """y = x . W^T + b with frozen W [N, K], b: both GEMMs (forward, dx = dy . W) on the split-bf16 kernel."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        k = weight.shape[1]
-        x2 = _dev(x.reshape(-1, k), "x")
-        m, n = x2.shape[0], weight.shape[0]
-        y = torch.empty(m, n, device=x.device, dtype=torch.float32)
-        bb = _dev(bias.detach(), "bias") if bias is not None else None
-        N.check(N.lab().skp_gemm_x3_nt_f32(x2.data_ptr(), _x3_planes(weight, False).data_ptr(),
-                                           bb.data_ptr() if bb is not None else None, y.data_ptr(), m, n, k, k, n, _stream()),
-                "skp_gemm_x3_nt_f32")
-        ctx.weight = weight
-        ctx.xshape = x.shape
-        return y.reshape(*x.shape[:-1], n)
-
-    @staticmethod
-    def backward(ctx, dy):
-        w = ctx.weight
-        n, k = w.shape
-        if k < X3_MIN_WIDTH:                                     # narrow dx: the library GEMM is faster there
-            return torch.matmul(dy, w), None, None
-        d2 = _dev(dy.reshape(-1, n), "dy")
-        m = d2.shape[0]
-        dx = torch.empty(m, k, device=dy.device, dtype=torch.float32)
-        N.check(N.lab().skp_gemm_x3_nt_f32(d2.data_ptr(), _x3_planes(w, True).data_ptr(), None, dx.data_ptr(), m, k, n, n, k,
-                                           _stream()), "skp_gemm_x3_nt_f32")
-        return dx.reshape(ctx.xshape), None, None
-
-
-def linear_auto(x, weight, bias=None):
-    """nn.Linear of a frozen block: library GEMM (fp32), or the split-bf16 experiment when SKP_EMULATED_F32=1."""
-    if EMULATED_F32 and linear_x3_wanted(x, weight) and (bias is None or not bias.requires_grad):
-        return LinearX3Fn.apply(x, weight, bias)
-    return torch.nn.functional.linear(x, weight, bias)
-
-
 _QKV_CACHE = {}
 
 
@@ -1360,7 +1235,7 @@ def weight_stack(ws):
     return w3
 
 
-QKV_STACKED = os.environ.get("SKP_QKV_STACKED", "1") != "0"   # A/B switch: one batched GEMM with a broadcast A operand
+QKV_STACKED = True   # one batched GEMM with a broadcast A operand
 
 
 def _qkv_forward(x, wq, wk, wv):
@@ -1399,7 +1274,7 @@ class QKVProjFn(torch.autograd.Function):
         return dx.reshape(*shp[:-1], wq.shape[1]), None, None, None
 
 
-QKV_ACCUM = os.environ.get("SKP_QKV_ACCUM", "1") != "0"       # A/B switch
+QKV_ACCUM = True
 
 
 def qkv_proj(x, wq, wk, wv):
@@ -1460,7 +1335,7 @@ def self_attention_block(x, wq, wk, wv, heads: int, scale: float):
     frozen = not (wq.requires_grad or wk.requires_grad or wv.requires_grad)
     if (QKV_STACKED and QKV_ACCUM and not FLASH_SPLIT and x.is_cuda and x.dim() == 3 and frozen and x.requires_grad
             and torch.is_grad_enabled() and wq.shape == wk.shape == wv.shape and wq.shape[0] % heads == 0
-            and (wq.shape[0] // heads) in FA2_HEAD_DIMS and not os.environ.get("SKP_FLASH_GEN", "") == "1"):
+            and (wq.shape[0] // heads) in FA2_HEAD_DIMS):
         return SelfAttnQKVFn.apply(_dev(x, "x"), wq, wk, wv, int(heads), float(scale))
     q, k, v = qkv_proj(x, wq, wk, wv)
     return self_attention(q, k, v, heads, scale)
@@ -1486,7 +1361,7 @@ def conv3x3_s2_supported(x, weight) -> bool:
             and w % 32 == 0 and max(b * ci * h * w, b * co * (h // 2) * (w // 2), 9 * ci * co) * 4 < 2 ** 31)
 
 
-S2_BWD_OWN = os.environ.get("SKP_S2_BWD", "own") != "lib"      # A/B switch: "lib" = the library's backward-data
+S2_BWD_OWN = True
 
 
 class ConvS2Fn(torch.autograd.Function):

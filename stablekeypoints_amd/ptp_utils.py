@@ -17,7 +17,6 @@ What changes under the hood
 from __future__ import annotations
 
 import abc
-import os
 from typing import Optional
 
 import numpy as np
@@ -91,7 +90,7 @@ MAX_STORED_SEQ = 32 ** 2       # ptp_utils.py:510
 # ---------------------------------------------------------------------------------------------
 # context projections of one forward                          reference ptp_utils.py:513-520
 # ---------------------------------------------------------------------------------------------
-CTX_KV_BATCHED = os.environ.get("SKP_CTX_KV", "1") != "0"       # A/B switch
+CTX_KV_BATCHED = True        # False (tests): every layer projects the context for itself
 _CTX_KV = {}                 # id(CrossAttention module) -> (k, v) [1,T,C] of the forward in flight
 
 

@@ -32,3 +32,17 @@ def golden():
     def load(name):
         return dict(np.load(os.path.join(GOLDEN, name)))
     return load
+
+
+@pytest.fixture
+def tune():
+    """Developer overrides of the library's launch plans (include/skp.h: skp_tune_set), restored after the test."""
+    from stablekeypoints_amd import _native as N
+    touched = set()
+
+    def set_(key, value):
+        touched.add(key)
+        N.tune(key, value)
+    yield set_
+    for key in touched:
+        N.tune(key, 0)

@@ -499,11 +499,11 @@ def test_raw_filter_winograd_small_layers_vs_fp64(ops, B, ci, co, H, W, bias, re
     torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-4, atol=6e-5 * ref.abs().max().item())
     assert torch.equal(ops._conv3x3_f4r_raw(xg, ops._wino4r_filters(wg, False), bg, co, residual=rg), y)
     for split in ("1", "2"):                                     # the unsplit kernel form (bias / residual in its own epilogue) and a forced K split
-        os.environ["SKP_WINO_SPLIT"] = split
+        ops.N.tune("wino_split", int(split))
         try:
             ys = ops._conv3x3_f4r_raw(xg, ops._wino4r_filters(wg, False), bg, co, residual=rg)
         finally:
-            del os.environ["SKP_WINO_SPLIT"]
+            ops.N.tune("wino_split", 0)
         torch.testing.assert_close(ys.cpu().double(), ref.detach(), rtol=1e-4, atol=6e-5 * ref.abs().max().item())
     if ci % 64 == 0:                                             # the backward-data launch swaps the channel roles
         dx = ops._conv3x3_f4r_raw(gy.cuda(), ops._wino4r_filters(wg, True), None, ci)

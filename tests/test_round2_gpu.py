@@ -540,9 +540,12 @@ def test_fused_attention_backward_matches_two_kernel_form_and_is_reproducible(op
         q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
         grads = {}
         for mode in ("1", "0", "1"):
-            monkeypatch.setenv("SKP_FA2_FUSED", mode)
-            out = ops.self_attention(q, k, v, H, d ** -0.5)
-            grads.setdefault(mode, []).append([x.clone() for x in torch.autograd.grad(out, (q, k, v), w)])
+            ops.N.tune("fa2_two_kernel_bwd", 1 if mode == "0" else 0)
+            try:
+                out = ops.self_attention(q, k, v, H, d ** -0.5)
+                grads.setdefault(mode, []).append([x.clone() for x in torch.autograd.grad(out, (q, k, v), w)])
+            finally:
+                ops.N.tune("fa2_two_kernel_bwd", 0)
         for a, b in zip(*grads["1"]):
             assert torch.equal(a, b)
         for a, b in zip(grads["1"][0], grads["0"][0]):
@@ -577,52 +580,6 @@ def test_shortcut_as_batched_gemm_matches_conv1x1(ops):
     (gx,) = torch.autograd.grad(y, x, dy)
     (gr,) = torch.autograd.grad(ref, x, dy.double())
     torch.testing.assert_close(gx.double(), gr.double(), rtol=1e-4, atol=1e-4)
-
-
-@pytest.mark.parametrize("M,N,K,with_bias", [(512, 320, 320, True), (300, 96, 64, False), (2048, 1280, 640, True),
-                                              (77, 640, 768, False), (130, 2560, 320, True)])
-def test_split_bf16_gemm_is_as_accurate_as_fp32(ops, M, N, K, with_bias):
-    """Experiment path (SKP_EMULATED_F32): the three-term bf16 split GEMM against fp64; its error must stay within twice
-    the error of the fp32 library GEMM on the same inputs plus 2e-6 of the output scale (the library switches to more
-    accurate split-K kernels on skinny shapes), and the input gradient likewise."""
-    g = torch.Generator().manual_seed(41)
-    x = torch.randn(M, K, generator=g).cuda().requires_grad_(True)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
-    b = torch.randn(N, generator=g).cuda() if with_bias else None
-    dy = torch.randn(M, N, generator=g).cuda()
-    ref = torch.nn.functional.linear(x.double(), w.double(), b.double() if with_bias else None)
-    (gref,) = torch.autograd.grad(ref, x, dy.double())
-    y32 = torch.nn.functional.linear(x, w, b)
-    (g32,) = torch.autograd.grad(y32, x, dy)
-    y = ops.LinearX3Fn.apply(x, w, b)
-    gx = torch.empty_like(x)                                    # input gradient through the same kernel (transposed planes)
-    nat = ops.N
-    nat.check(nat.lab().skp_gemm_x3_nt_f32(dy.data_ptr(), ops._x3_planes(w, True).data_ptr(), None, gx.data_ptr(), M, K, N, N, K,
-                                           torch.cuda.current_stream().cuda_stream), "skp_gemm_x3_nt_f32")
-    e32, e3 = (y32.double() - ref).abs().max().item(), (y.double() - ref).abs().max().item()
-    ge32, ge3 = (g32.double() - gref.double()).abs().max().item(), (gx.double() - gref.double()).abs().max().item()
-    assert e3 <= 2.0 * e32 + 2e-6 * ref.abs().max().item(), (e3, e32)
-    assert ge3 <= 2.0 * ge32 + 2e-6 * gref.abs().max().item(), (ge3, ge32)
-    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
-
-
-def test_split_bf16_linear_autograd_and_dispatch(ops, monkeypatch):
-    """LinearX3Fn forward + input gradient on a wide layer (both GEMMs on the split kernel) vs fp64, and the dispatcher's
-    shape rule (wide outputs only, everything else on the library)."""
-    g = torch.Generator().manual_seed(42)
-    x = torch.randn(2, 1100, 2048, generator=g).cuda().requires_grad_(True)
-    w = (torch.randn(2560, 2048, generator=g) / 2048 ** 0.5).cuda()
-    b = torch.randn(2560, generator=g).cuda()
-    dy = torch.randn(2, 1100, 2560, generator=g).cuda()
-    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
-    (gref,) = torch.autograd.grad(ref, x, dy.double())
-    y = ops.LinearX3Fn.apply(x, w, b)
-    (gx,) = torch.autograd.grad(y, x, dy)
-    torch.testing.assert_close(y.double(), ref, rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(gx.double(), gref.double(), rtol=1e-5, atol=2e-5)
-    assert ops.linear_x3_wanted(x, w) and not ops.linear_x3_wanted(x, w[:320].contiguous()) and not ops.linear_x3_wanted(x[:, :100], w)
-    monkeypatch.setattr(ops, "EMULATED_F32", False)
-    assert torch.equal(ops.linear_auto(x, w, b), torch.nn.functional.linear(x, w, b))
 
 
 @pytest.mark.parametrize("pad", [1, 0])

@@ -252,13 +252,13 @@ def _fp64_map_and_grad(S, sides, H, T, R, sel, G):
     dict(sides=[8], H=2, T=9, R=6, B=1, K=2),                             # down-sampling
     dict(sides=[1, 2], H=4, T=16, R=8, B=1, K=4),                         # degenerate sides
 ])
-def test_sparse_map_backward_vs_fp64_and_dense(case, monkeypatch):
+def test_sparse_map_backward_vs_fp64_and_dense(case, monkeypatch, tune):
     """skp_attn_map_bwd_sparse_f32 (token-major sweep, sparse gradient rows) against fp64 autograd through
     F.interpolate(bicubic) + softmax, and against the dense-gradient kernels on the same inputs; repeat run bit-identical."""
     from stablekeypoints_amd import ops
     monkeypatch.setattr(ops, "MAP_BWD_MODE", "sweep")            # this test is the token-major sweep's (column sweep: round 4)
     if "bands" in case:
-        monkeypatch.setenv("SKP_MAP_BANDS", str(case["bands"]))
+        tune("map_bands", case["bands"])
     sides, H, T, R, B, K = (case[k] for k in ("sides", "H", "T", "R", "B", "K"))
     g = torch.Generator().manual_seed(7)
     NT = (T + 15) // 16 * 16
@@ -537,7 +537,7 @@ def test_stride2_conv_input_gradient_own_kernels_vs_fp64(B, ci, co, H, W, pad):
 
 @pytest.mark.parametrize("B,ci,co,H,S", [(2, 112, 64, 16, 2), (2, 112, 64, 16, 3), (2, 112, 96, 16, 4), (8, 208, 128, 32, 3),
                                          (8, 176, 256, 32, 4), (1, 48, 64, 24, 2)])
-def test_winograd_f4_uneven_k_splits_vs_fp64(monkeypatch, B, ci, co, H, S):
+def test_winograd_f4_uneven_k_splits_vs_fp64(tune, B, ci, co, H, S):
     """K splits that do not divide the 16-channel stages (the last workgroup of a unit takes the remainder): both workgroup
     forms (64 channels x 32 tiles; 128 channels x 16 tiles at >= 256 tiles), partial sums reduced in split order -- against
     fp64 conv2d, and twice for the same bits."""
@@ -548,14 +548,14 @@ def test_winograd_f4_uneven_k_splits_vs_fp64(monkeypatch, B, ci, co, H, S):
     b = torch.randn(co, generator=g)
     res = torch.randn(B, co, H, H, generator=g)
     ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
-    monkeypatch.setenv("SKP_WINO_SPLIT", str(S))
+    tune("wino_split", S)
     nbytes = ops.N.lib().skp_conv3x3_f4_workspace(B, ci, co, H, H)
     assert nbytes == S * B * co * H * H * 4                 # the forced split is the plan
     U = ops._wino4_filters(w.cuda(), False)
     y = ops._conv3x3_f4_raw(x.cuda(), U, b.cuda(), co, residual=res.cuda())
     torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-4, atol=6e-5 * ref.abs().max().item())
     assert torch.equal(ops._conv3x3_f4_raw(x.cuda(), U, b.cuda(), co, residual=res.cuda()), y)
-    monkeypatch.delenv("SKP_WINO_SPLIT")
+    tune("wino_split", 0)
     y1 = ops._conv3x3_f4_raw(x.cuda(), U, b.cuda(), co, split=False, residual=res.cuda())
     torch.testing.assert_close(y, y1, rtol=1e-4, atol=2e-5 * ref.abs().max().item())
 

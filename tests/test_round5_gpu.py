@@ -101,94 +101,6 @@ def test_optimize_embedding_host_folder_prefetch_is_order_identical(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Winograd F(4x4,3x3) on the bf16 matrix cores with three-term operand splits (csrc/skp_conv_wino4s.hip)
-# ---------------------------------------------------------------------------------------------------------------------
-def _conv_ref64(x, w, b, res=None):
-    y = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
-    return y if res is None else y + res.double()
-
-
-@pytest.mark.parametrize("B,ci,co,H,W,bias,res,kind", [
-    (2, 32, 64, 8, 8, True, False, "randn"),            # one ragged tile block (8 of 32 tiles), 2 stages
-    (1, 16, 64, 4, 12, False, True, "randn"),           # a single stage: prologue -> last-stage halves only
-    (3, 64, 128, 12, 20, True, True, "randn"),          # two channel groups, tiles not a multiple of 32, image borders inside blocks
-    (8, 128, 128, 64, 64, True, False, "randn"),        # the VAE launch family: 8 stages, XCD-band order (64 tile blocks)
-    (2, 320, 320, 16, 16, False, False, "randn"),       # unit-grouped order, K-split plan
-    (8, 1280, 640, 8, 8, False, True, "randn"),         # 80 stages, K splits + reduction kernel with residual
-    (2, 128, 128, 32, 32, True, False, "mean50"),       # mean 50 / spread 0.1: the statistics case of the GroupNorm tests
-    (2, 128, 64, 32, 32, True, False, "tiny"),          # inputs ~1e-5: bf16 terms keep the fp32 exponent range
-    (2, 128, 64, 32, 32, True, False, "huge"),          # inputs ~1e5
-])
-def test_split_bf16_winograd_conv_vs_fp64(B, ci, co, H, W, bias, res, kind):
-    """skp_conv3x3_f4s_f32 (three bf16 terms per fp32 operand, six products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)
-    against fp64 conv2d, forward (+ bias, + residual) and the input-gradient launch (rotated / transposed filter).
-    Acceptance is ACCURACY: with the same accumulation chain (both kernels unsplit) the error against fp64 is at most 1.5x the
-    fp32-instruction kernel's on the same input (plus 1e-7 of the output scale where both are at rounding level), at every
-    input scale; the result is deterministic; the fp32 kernels' absolute tolerance (6e-5 of the output maximum) holds too."""
-    from stablekeypoints_amd import ops
-    g = torch.Generator().manual_seed(31)
-    x = torch.randn(B, ci, H, W, generator=g)
-    x = {"randn": x, "mean50": 50.0 + 0.1 * x, "tiny": x * 1e-5, "huge": x * 1e5}[kind]
-    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
-    b = torch.randn(co, generator=g) * x.abs().mean() if bias else None
-    r = torch.randn(B, co, H, W, generator=g) * x.abs().mean() if res else None
-    gy = torch.randn(B, co, H, W, generator=g)
-    ref = _conv_ref64(x, w, b, r)
-    dref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
-    xg, wg, gyg = x.cuda(), w.cuda(), gy.cuda()
-    bg, rg = (None if b is None else b.cuda()), (None if r is None else r.cuda())
-    assert ops.N.lib().skp_conv3x3_f4s_ok(B, ci, co, H, W) == 1
-    y = ops.conv3x3_f4s(xg, wg, bg, rg)
-    y32 = ops._conv3x3_f4_raw(xg, ops._wino4_filters(wg, False), bg, co, residual=rg)
-    scale = ref.abs().max().item()
-    e_s = (y.cpu().double() - ref).abs().max().item() / scale
-    e_32 = (y32.cpu().double() - ref).abs().max().item() / scale
-    print(f"fwd {kind}: split {e_s:.2e}  fp32-instruction kernel {e_32:.2e}  ratio {e_s / e_32:.2f}")
-    # default plans: the two kernels cut the Cin / 16 stages into DIFFERENT numbers of K splits (different workgroup tiles), i.e.
-    # different rounding-chain lengths: bounded loosely here, compared like with like below
-    assert e_s <= 2.0 * e_32 + 1e-7 and e_s < 6e-5
-    assert torch.equal(ops.conv3x3_f4s(xg, wg, bg, rg), y)                       # deterministic
-    # like with like: the UNSPLIT launches of both kernels (the accumulation chain is Cin / 16 stages long in both; the default
-    # plans above cut it into K splits for small grids, which also shortens the rounding chain)
-    y1 = ops._conv3x3_f4s_raw(xg, ops._wino4s_filters(wg, False), bg, co, split=False, residual=rg)
-    y1_32 = ops._conv3x3_f4_raw(xg, ops._wino4_filters(wg, False), bg, co, split=False, residual=rg)
-    e1, e1_32 = ((t.cpu().double() - ref).abs().max().item() / scale for t in (y1, y1_32))
-    print(f"    unsplit: split {e1:.2e}  fp32-instruction kernel {e1_32:.2e}  ratio {e1 / e1_32:.2f}")
-    assert e1 <= 1.5 * e1_32 + 1e-7 and e1 < 6e-5
-    if ci % 64 == 0:                                                             # input gradient: Cout of that launch is Cin
-        dx = ops._conv3x3_f4s_raw(gyg, ops._wino4s_filters(wg, True), None, ci, split=False)      # unsplit, both kernels
-        dx32 = ops._conv3x3_f4_raw(gyg, ops._wino4_filters(wg, True), None, ci, split=False)
-        assert torch.isfinite(ops.conv3x3_f4s(gyg, wg, backward=True)).all()                         # the default (K-split) launch runs
-        ds = dref.abs().max().item()
-        eb, eb32 = (dx.cpu().double() - dref).abs().max().item() / ds, (dx32.cpu().double() - dref).abs().max().item() / ds
-        print(f"bwd-data: split {eb:.2e}  fp32 {eb32:.2e}  ratio {eb / eb32:.2f}")
-        assert eb <= 1.5 * eb32 + 1e-7
-
-
-def test_split_bf16_winograd_conv_statistics_and_gate():
-    """The split kernel's epilogue statistics ({mean, sum of squared deviations} per 16-tile block of the output, the next
-    GroupNorm's input) against torch on the kernel's own output, and the shape gate / error codes of the C ABI."""
-    from stablekeypoints_amd import ops, _native as N
-    lib = N.lib()
-    g = torch.Generator().manual_seed(5)
-    B, ci, co, H, W = 2, 64, 128, 64, 32
-    x = torch.randn(B, ci, H, W, generator=g).cuda()
-    w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
-    b = torch.randn(co, generator=g).cuda()
-    nblk = lib.skp_conv3x3_f4s_stats_blocks(B, ci, co, H, W)
-    assert nblk == H * W // 256
-    st = torch.full((B, co, nblk, 2), float("nan"), device="cuda")
-    y = ops._conv3x3_f4s_raw(x, ops._wino4s_filters(w, False), b, co, stats=st)
-    assert torch.equal(y, ops._conv3x3_f4s_raw(x, ops._wino4s_filters(w, False), b, co, split=False))
-    t = y.reshape(B, co, H // 4, 4, W // 4, 4).permute(0, 1, 2, 4, 3, 5).reshape(B, co, nblk, 256).double()
-    torch.testing.assert_close(st[..., 0].double(), t.mean(-1), rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(st[..., 1].double(), ((t - t.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
-    assert lib.skp_conv3x3_f4s_ok(1, 16, 32, 8, 8) == 0 and lib.skp_conv3x3_f4s_ok(1, 24, 64, 8, 8) == 0 and lib.skp_conv3x3_f4s_ok(1, 16, 64, 6, 8) == 0
-    rc = lib.skp_conv3x3_f4s_f32(x.data_ptr(), ops._wino4s_filters(w, False).data_ptr(), None, None, y.data_ptr(), None, None, 1, 16, 32, 8, 8, None)
-    assert rc == N.lib().skp_conv3x3_f4s_f32(x.data_ptr(), ops._wino4s_filters(w, False).data_ptr(), None, None, y.data_ptr(), None, None, 1, 16, 32, 8, 8, None) != 0
-
-
-# ---------------------------------------------------------------------------------------------------------------------
 # flash attention forward on the bf16 matrix cores with three-term operand splits (csrc/skp_flash_attn_s.hip)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,Bk,H,N,Nk,d", [

@@ -22,9 +22,7 @@ SHAPES = {"gn": (8, 128, 128, 512, "gn"), "plain": (8, 128, 128, 512, "plain"), 
           # the raw-filter form (skp_conv3x3_f4r_f32: input transform + convolution + K-split reduction per call)
           "r1280_8": (8, 1280, 1280, 8, "raw"), "r2560_8": (8, 2560, 1280, 8, "raw"), "r1280_16": (8, 1280, 1280, 16, "raw"),
           "r2560_16": (8, 2560, 1280, 16, "raw"),
-          # the split (3 x bf16) form, skp_conv3x3_f4s_f32; sp_pN: stage-time probes (512^2, 4 rows, N input channels)
-          "sp512": (8, 128, 128, 512, "split"), "sp256": (8, 256, 256, 256, "split"), "sp128": (8, 512, 512, 128, "split"),
-          "sp_p128": (4, 128, 128, 512, "split"), "sp_p256": (4, 256, 128, 512, "split"), "sp_p384": (4, 384, 128, 512, "split"),
+          # pN: stage-time probes (512^2, 4 rows, N input channels)
           "p128": (4, 128, 128, 512, "plain"), "p256": (4, 256, 128, 512, "plain"), "p384": (4, 384, 128, 512, "plain")}
 
 
@@ -40,12 +38,10 @@ def worker(names, iters):
         x = torch.randn(B, ci, sz, sz, generator=g).cuda()
         w = (torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)).cuda()
         y = torch.empty(B, co, sz, sz, device="cuda")
-        U = ops._wino4r_filters(w, False) if form == "raw" else ops._wino4s_filters(w, False) if form == "split" else ops._wino4_filters(w, False)
+        U = ops._wino4r_filters(w, False) if form == "raw" else ops._wino4_filters(w, False)
         nblk = ops.conv3x3_stats_blocks(x.shape, w.shape)
         if form == "raw":
             fn = lambda: ops._conv3x3_f4r_raw(x, U, None, co, out=y)
-        elif form == "split":
-            fn = lambda: ops._conv3x3_f4s_raw(x, U, None, co, out=y)
         elif form == "gn":
             stats = torch.empty(B, co, nblk, 2, device="cuda")
             coef = torch.stack([torch.full((B, ci), 0.7), torch.full((B, ci), 0.1)], dim=-1).cuda().contiguous()

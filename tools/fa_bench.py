@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """A/B timing + cross-check of the flash-attention kernel generations / tile variants at the step's launch shapes.
     python tools/fa_bench.py [--rows 8] [--iters 10] [--bwd]
-Environment switches read by the library per launch: SKP_FLASH_GEN=1 (first generation), SKP_FA2_VARIANT=n,
-SKP_FA2_FUSED=0 (two-kernel backward; a variant written "n+2k" sets it)."""
+Variants: "0" = the library's choice, "0+2k" = the two-kernel backward at the fused form's shapes (skp_tune_set)."""
 import argparse
 import os
 import sys
@@ -31,7 +30,7 @@ def main():
     ap.add_argument("--rows", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bwd", action="store_true")
-    ap.add_argument("--variants", default="gen1,0,1,2,3")
+    ap.add_argument("--variants", default="0,0+2k")
     ap.add_argument("--shapes", default="4096x8x40,1024x8x80,9216x5x64,4096x10x64")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -44,12 +43,7 @@ def main():
         flops = 4.0 * N * N * d * B * H
         ref = gref = None
         for var in a.variants.split(","):
-            if var == "gen1":
-                os.environ["SKP_FLASH_GEN"] = "1"
-            else:
-                os.environ["SKP_FLASH_GEN"] = "0"
-                os.environ["SKP_FA2_VARIANT"] = var.split("+")[0]
-            os.environ["SKP_FA2_FUSED"] = "0" if var.endswith("+2k") else "1"
+            ops.N.tune("fa2_two_kernel_bwd", 1 if var.endswith("+2k") else 0)
             try:
                 out = ops.self_attention(q, k, v, H, d ** -0.5)
                 torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GroupNorm + SiLU folded into the Winograd patch load vs the separate apply pass, per launch shape (us; events).
-SKP_GN_FOLD_MAX_COUT=<n> widens the fold's gate beyond one channel group (the SiLU is then redone per channel group)."""
+ops.N.tune("gn_fold_max_cout", n) widens the fold's gate beyond one channel group (the SiLU is then redone per channel group)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

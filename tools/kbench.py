@@ -73,17 +73,6 @@ def main():
         e1.record(); torch.cuda.synchronize()
         print(f"{name:28s} {e0.elapsed_time(e1) / a.iters * 1e3:9.1f} us")
 
-    if a.what == "map":       # A/B of the quad-broadcast H phase (SKP_MAP_QUAD=0: four LDS reads per token quad) + agreement
-        import os
-        outs = {}
-        for mode in ("0", "1"):
-            os.environ["SKP_MAP_QUAD"] = mode
-            timed(f"attn_map_fwd quad={mode}", lambda: N.check(lib.skp_attn_map_fwd_f32(sp, si, 4, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "f"))
-            timed(f"attn_map_bwd quad={mode}", lambda: N.check(lib.skp_attn_map_bwd_f32(sp, dp, si, 4, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "b"))
-            outs[mode] = (M.clone(), lse.clone(), [x.clone() for x in dS])
-        print("max |M diff|", float((outs["0"][0] - outs["1"][0]).abs().max()), "max |lse diff|", float((outs["0"][1] - outs["1"][1]).abs().max()),
-              "max rel dS diff", max(float((x - y).abs().max() / x.abs().max()) for x, y in zip(outs["0"][2], outs["1"][2])))
-        return
     timed("attn_map_fwd", lambda: N.check(lib.skp_attn_map_fwd_f32(sp, si, 4, B, H, T, R, M.data_ptr(), lse.data_ptr(), st), "f"))
     timed("attn_map_bwd (A+B)", lambda: N.check(lib.skp_attn_map_bwd_f32(sp, dp, si, 4, B, H, T, R, dM.data_ptr(), lse.data_ptr(), ws.data_ptr(), st), "b"))
     timed("qk_logits x4", lambda: [ops.qk_logits(q, k, H, sc) for q, k, sc in zip(qs, ks, scales)])
