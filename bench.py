@@ -655,11 +655,20 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    c0 = time.thread_time()                                       # CPU time of the launch thread (the only host work of a rank)
     for _ in range(a.steps):
         last = one_step()
+    c_launch = time.thread_time() - c0                            # ... until its last launch is queued (the waits below are idle time)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
+    # one more step from an idle GPU: when does the launch thread return, when is the GPU done?  (launch_ms < total_ms: the
+    # step is GPU-bound and the host has slack; launch_ms ~ total_ms: launch-bound -- what a captured hipGraph would remove)
+    ti = time.perf_counter()
+    one_step()
+    t_issue = time.perf_counter() - ti
+    torch.cuda.synchronize()
+    t_idle_total = time.perf_counter() - ti
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -819,7 +828,9 @@ def main():
             "f32_split": f32_split,
             "traffic_live_kernels": sorted(live) if live else None,
             "cpu_baseline": cpu_stats, "verify": verify, "collective_check": coll,
-            "loss": float(last[0]), "setup_s": t_build, "cpu_baseline_s": t_cpu, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
+            "loss": float(last[0]), "setup_s": t_build, "cpu_baseline_s": t_cpu,
+            "launch_thread_cpu_ms_per_step": c_launch / a.steps * 1e3,
+            "step_from_idle": {"launch_thread_returns_ms": t_issue * 1e3, "gpu_done_ms": t_idle_total * 1e3}, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
             "weights_init": weights_init,
         }
         if line["roofline"]["traffic"]:

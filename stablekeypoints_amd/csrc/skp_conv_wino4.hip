@@ -386,7 +386,9 @@ __device__ unsigned long long w4r_stamps[2][64];
 #endif
 // PART: the launch is K-split -- the output is a partial sum for skp_wino4_reduce_kernel (which adds bias / residual): the
 // epilogue carries no bias / residual prefetch (128 registers less at the end of the stage loop).
-template <bool PART>
+// NTB: tile blocks of 16 the wave multiplies (2: the 32 tiles of the workgroup; 1: launches with <= 16 tiles -- the 8^2 layers of a
+// 1- or 2-image step, config 3's per-rank shape -- where the second block would be all padding: half the MFMAs per stage).
+template <bool PART, int NTB = 2>
 __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     extern __shared__ f32x4 vst[];                   // [2][36][4][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -485,9 +487,8 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
         const int c16n = c16_0 + min(s + 1, nsteps - 1);
         f32x4 va[3][2];                              // LDS operands two positions ahead (three: measured no faster)
         va[0][0] = vb[0];
-        va[0][1] = vb[16];
         va[1][0] = vb[128];
-        va[1][1] = vb[128 + 16];
+        if (NTB == 2) { va[0][1] = vb[16]; va[1][1] = vb[128 + 16]; }
         w4_unroll([&](auto pc) {
             constexpr int p = decltype(pc)::value, i = p / 6, j = p - 6 * i;
             if (p == 0) load_g(gn, c16n);                // the taps first: they come from HBM, the tiles (L2 / MALL) queue behind them
@@ -495,12 +496,12 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
             if (i < 5) u_piece(g, i + 1, j, ur[(i + 1) & 1]);
             if (p + 2 < 36) {
                 va[(p + 2) % 3][0] = vb[(p + 2) * 128];
-                va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];
+                if (NTB == 2) va[(p + 2) % 3][1] = vb[(p + 2) * 128 + 16];
             }
             w4_unroll([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
                 w4c_mfma<p, 0>(accv, ur[i & 1][j][m], va[p % 3][0][m]);
-                w4c_mfma<p, 1>(accv, ur[i & 1][j][m], va[p % 3][1][m]);
+                if constexpr (NTB == 2) w4c_mfma<p, 1>(accv, ur[i & 1][j][m], va[p % 3][1][m]);
             }, std::make_integer_sequence<int, 4>{});
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, 36>{});
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
 #pragma unroll
                 for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(o[oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }, std::make_integer_sequence<int, 2>{});
+            }, std::make_integer_sequence<int, NTB>{});
         }, std::make_integer_sequence<int, 4>{});
         W4R_STAMP(40);
 #ifdef W4R_STAMPS
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
     auto load_res = [&](int r) {
         const int co = n0 + 4 * kq + r;
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
+        for (int tb = 0; tb < NTB; ++tb) {
             const bool ok = t_ok[tb] && co < a.Cout;
             const int vo = (o_base[tb] + co * HW) * 4;
 #pragma unroll
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void skp_wino4r_conv_kernel(Wino4Args a) {
 #pragma unroll
             for (int oy = 0; oy < 4; ++oy) skp_buf_store_f32x4(rr[r][tb][oy], yrs, ok ? vo + oy * a.W * 4 : SKP_OOB, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }, std::make_integer_sequence<int, 2>{});
+        }, std::make_integer_sequence<int, NTB>{});
     }, std::make_integer_sequence<int, 4>{});
 }
 
@@ -977,6 +978,7 @@ static bool wino4r_shape_ok(int B, int Cin, int Cout, int H, int W) {
     if (Cin >= 1280 && Cout >= 1280) return tiles <= 1536;
     return tiles <= 512 && (Cin >= 1920 || Cout >= 1920) && Cin >= 640 && Cout >= 640;
 }
+constexpr double W4R_STAGE1_US = 2.7;
 static int wino4r_plan(int B, int Cin, int Cout, int H, int W) {
     const int tiles = B * (H / 4) * (W / 4);
     const int nsteps = Cin / 16;
@@ -987,12 +989,13 @@ static int wino4r_plan(int B, int Cin, int Cout, int H, int W) {
     int best = 1;
     double best_cost = 1e30;
     // measured (cycle stamps, W4R_STAMPS builds): 4.8 us per stage, ~2.1 us prologue + ~5.3 us epilogue + dispatch per workgroup
-    const double stage_us = 4.8;
+    // (one 16-tile block per wave, <= 16 tiles: half the MFMAs per stage, half the epilogue)
+    const double stage_us = tiles <= 16 ? W4R_STAGE1_US : 4.8, over = tiles <= 16 ? 2.0 : 2.5;
     for (int S = 1; S <= 16; ++S) {
         const int per = (nsteps + S - 1) / S;
         if ((S - 1) * per >= nsteps) continue;
         const Wino4Grid g = wino4r_grid(Cout, tiles, S);
-        double cost = g.rounds * (per + 2.5) * stage_us;
+        double cost = g.rounds * (per + over) * stage_us;
         if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
         if (cost < best_cost * (S > 1 ? 0.97 : 1.0)) { best_cost = cost; best = S; }
     }
@@ -1198,6 +1201,10 @@ extern "C" int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bia
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)skp_wino4r_conv_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const Wino4Grid g = wino4r_grid(Cout, a.nTiles, S);
@@ -1208,7 +1215,10 @@ extern "C" int skp_conv3x3_f4r_f32(const void* x, const void* R, const void* bia
     hipLaunchKernelGGL(skp_wino4r_input_kernel, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, st, (const float*)x, Vg, B, Cin, H, W,
                        a.tilesX, a.tilesPerImg, a.nTiles, a.vpad);
     const dim3 grid = g.tb_per_xcd ? dim3(g.gx, 1, S) : dim3(g.gx, 1, 1);
-    if (S > 1) hipLaunchKernelGGL(skp_wino4r_conv_kernel<true>, grid, dim3(256), lds, st, a);
+    if (a.nTiles <= 16) {                           // one 16-tile block per wave
+        if (S > 1) hipLaunchKernelGGL((skp_wino4r_conv_kernel<true, 1>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((skp_wino4r_conv_kernel<false, 1>), grid, dim3(256), lds, st, a);
+    } else if (S > 1) hipLaunchKernelGGL(skp_wino4r_conv_kernel<true>, grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL(skp_wino4r_conv_kernel<false>, grid, dim3(256), lds, st, a);
     int rc = skp_launch_status();
     if (rc || S == 1) return rc;

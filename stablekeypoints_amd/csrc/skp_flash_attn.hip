@@ -431,7 +431,8 @@ __global__ __launch_bounds__(512, 1) void skp_fa2_fwd_halves_kernel(const float*
         __syncthreads();
     }
     // merge: the second half parks (o, m, l partial) in LDS, the first half combines in fixed order and writes
-    constexpr int MST = 4 * F::CT + 2;                          // floats per lane
+    constexpr int MST = 4 * F::CT + 4;                          // floats per lane (o tuples, m, l, pad: 16-byte rows for ds_*_b128)
+    static_assert(MST % 4 == 0, "the per-lane record is read and written with 128-bit LDS operations");
     float* mb = smem + (size_t)(wq * 64 + lane) * MST;
     if (half == 1) {
 #pragma unroll
@@ -970,7 +971,7 @@ template <int D>
 static int fa2_launch_fwd_halves(const float* q, const float* k, const float* v, float* out, float* lse, int B, int H, int N, int Nk,
                                  int kvb, float scale, hipStream_t st) {
     using F = FA2<D>;
-    constexpr size_t tiles = (size_t)4 * F::TILE * sizeof(float), merge = (size_t)256 * (4 * F::CT + 2) * sizeof(float);
+    constexpr size_t tiles = (size_t)4 * F::TILE * sizeof(float), merge = (size_t)256 * (4 * F::CT + 4) * sizeof(float);
     const size_t lds = tiles > merge ? tiles : merge;
     static bool attr = false;
     if (!attr) {

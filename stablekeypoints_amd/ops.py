@@ -458,8 +458,9 @@ class MapLossesFn(torch.autograd.Function):
         # per-image launches were 77 workgroups of 40 us each, twelve of them per step); per-token results are what the
         # per-image calls give, bit for bit
         strategy = meta["strategy"]
+        # (a caller-supplied score function is honoured: only the stock order of optimize.token_order is batched)
         batched = (strategy in ("gaussian", "entropy", "consistent") and T <= SELECT_MAX_TOKENS and n_cand <= SELECT_MAX_CANDIDATES
-                   and K >= 2 and MAP_LOSSES_BATCHED)
+                   and K >= 2 and MAP_LOSSES_BATCHED and getattr(meta.get("score_fn"), "_skp_stock_order", False))
         if batched:
             flat = M.reshape(B * T, R, R)
             st_all = token_stats(flat[:n * T], num_subjects=ns, sigma=sigma, want_kl=strategy == "gaussian",
@@ -1220,18 +1221,19 @@ def _qkv_stack(wq, wk, wv):
 
 
 def weight_stack(ws):
-    """[len(ws), N, K] stack of frozen [N, K] weights, made once per list of parameters (their identities / versions are
-    checked on every use, like the other derived buffers of frozen weights)."""
+    """[len(ws), N, K] stack of frozen [N, K] weights (~200 MB over SD-1.5's attention projections), one entry per list of
+    parameters: keyed by the identity of the first one, re-made -- in place of the old entry, which is thereby released -- whenever
+    a parameter's storage or version has moved (`.to()`, dtype change, `load_state_dict`), dropped with its model."""
     import weakref
-    key = tuple(w.data_ptr() for w in ws) + (tuple(ws[0].shape), ws[0].device)
-    ver = tuple(w._version for w in ws)
+    key = (id(ws[0]), len(ws))
+    tag = tuple((w._version, w.data_ptr(), w.device, w.dtype) for w in ws)
     hit = _QKV_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[2]() is ws[0]:
+    if hit is not None and hit[0] == tag and hit[2]() is ws[0]:
         return hit[1]
     w3 = torch.stack([w.detach() for w in ws]).contiguous()
     for dead in [k_ for k_, v_ in _QKV_CACHE.items() if v_[2]() is None]:     # stacks of models that are gone
         del _QKV_CACHE[dead]
-    _QKV_CACHE[key] = (ver, w3, weakref.ref(ws[0]))
+    _QKV_CACHE[key] = (tag, w3, weakref.ref(ws[0]))
     return w3
 
 

@@ -203,6 +203,9 @@ def token_order(attn_map, strategy, num_subjects, sigma):
     raise NotImplementedError(strategy)
 
 
+token_order._skp_stock_order = True         # ops.MapLossesFn batches the statistics of all images only for this scoring
+
+
 def _group_losses(controller, thetas, args, n):
     """(sum_i equiv_i, sum_i sharp_i) of the 2n stored rows.  Default: ONE autograd node from the hooked layers' q / k to
     the two loss sums (ops.MapLossesFn), whose backward hands the map kernels the gradient as K selected rows per batch

@@ -94,7 +94,12 @@ CTX_KV_BATCHED = True        # False (tests): every layer projects the context f
 _CTX_KV = {}                 # id(CrossAttention module) -> (k, v) [1,T,C] of the forward in flight
 
 
-def _context_kv_begin(unet, context):
+def _ctx_layer_ok(m, width):
+    return (m.to_k.bias is None and m.to_v.bias is None and not m.to_k.weight.requires_grad and not m.to_v.weight.requires_grad
+            and m.to_k.weight.shape[1] == width and "forward" not in m.to_k.__dict__ and "forward" not in m.to_v.__dict__)
+
+
+def _context_kv_begin(unet, context, early_exit=False):
     """k = to_k(context), v = to_v(context) of the cross-attention layers for the ONE shared context row, before the UNet
     runs: the reference expands the learned embedding to the batch and projects it inside every layer (B x 77 rows through
     2 x 16 small GEMMs, as many again backward plus their accumulation adds).  The rows are identical, the weights frozen
@@ -106,17 +111,20 @@ def _context_kv_begin(unet, context):
     if not (CTX_KV_BATCHED and context.is_cuda and context.dim() == 3 and context.shape[0] == 1):
         return
     plan = getattr(unet, "_skp_ctx_plan", None)
-    if plan is None:
+    # the plan holds only layers whose projections are frozen, bias-free and unpatched -- re-checked on every forward (32
+    # modules): a layer that was unfrozen or re-patched since must project for itself again, or its weights would silently
+    # get no gradient
+    if plan is None or not all(_ctx_layer_ok(m, context.shape[-1]) for m in plan["mods"]):
         mods = [m.attn2 for m in unet.modules() if m.__class__.__name__ == "BasicTransformerBlock" and hasattr(m, "attn2")]
-        mods = [m for m in mods if m.to_k.bias is None and m.to_v.bias is None and not m.to_k.weight.requires_grad
-                and not m.to_v.weight.requires_grad and m.to_k.weight.shape[1] == context.shape[-1]
-                and "forward" not in m.to_k.__dict__ and "forward" not in m.to_v.__dict__]
-        plan = {"mods": mods, "used": None, "ids": {id(m) for m in mods}}
+        mods = [m for m in mods if _ctx_layer_ok(m, context.shape[-1])]
+        plan = {"mods": mods, "used": {}, "ids": {id(m) for m in mods}}
         unet._skp_ctx_plan = plan
-    mods = plan["mods"] if plan["used"] is None else [m for m in plan["mods"] if id(m) in plan["used"]]
-    if plan["used"] is None:
-        plan["used"] = set()
-    _CTX_KV["plan"] = plan
+    # which layers consume their pair depends on where the forward ends: one record per mode (early exit / full forward)
+    used = plan["used"].get(bool(early_exit))
+    mods = plan["mods"] if used is None else [m for m in plan["mods"] if id(m) in used]
+    if used is None:
+        used = plan["used"][bool(early_exit)] = set()
+    _CTX_KV["plan"] = {"ids": plan["ids"], "used": used}
     groups = {}
     for m in mods:
         groups.setdefault(m.to_k.weight.shape[0], []).append(m)
@@ -125,7 +133,7 @@ def _context_kv_begin(unet, context):
         w = ops.weight_stack([t for m in ms for t in (m.to_k.weight, m.to_v.weight)])        # [2n, C, Dctx], made once
         kv = torch.bmm(ctx2.unsqueeze(0).expand(w.shape[0], -1, -1), w.transpose(1, 2)).unbind(0)
         for i, m in enumerate(ms):
-            _CTX_KV[id(m)] = (kv[2 * i].unsqueeze(0), kv[2 * i + 1].unsqueeze(0), unet._skp_ctx_plan["used"])
+            _CTX_KV[id(m)] = (kv[2 * i].unsqueeze(0), kv[2 * i + 1].unsqueeze(0), used)
 
 
 def _context_kv_end():
@@ -311,7 +319,7 @@ def find_pred_noise(ldm, image, context, noise_level=-1, device="cuda", noise=No
         for c in controllers.values():
             c.stop_after = MAX_STORED_LAYERS
     try:
-        _context_kv_begin(ldm.unet, context)
+        _context_kv_begin(ldm.unet, context, early_exit=bool(early_exit and controllers is not None))
         pred_noise = ldm.unet(noisy_image, t.repeat(b), context.expand(b, -1, -1) if context.shape[0] == 1 else context)["sample"]
     except StopForward:
         pred_noise = None

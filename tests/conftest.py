@@ -46,3 +46,12 @@ def tune():
     yield set_
     for key in touched:
         N.tune(key, 0)
+
+
+@pytest.fixture(scope="session")
+def sd15_cpu():
+    """The full-width SD-1.5 tree on the HOST (seeded synthetic weights: the same tensors `load_ldm("cuda", "sd15")` draws), built
+    once per session for the oracle's reference-order CPU steps (each test registers its own reference hook on it)."""
+    from stablekeypoints_amd.optimize_token import load_ldm
+    cpu, _, _ = load_ldm("cpu", "sd15", feature_upsample_res=128)
+    return cpu

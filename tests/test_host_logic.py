@@ -578,7 +578,10 @@ def test_weight_stack_is_cached_per_parameter_list_and_follows_versions():
     s2 = ops.weight_stack([a, b])
     assert s2 is not s1 and torch.equal(s2[1], b.detach())
     n = len(ops._QKV_CACHE)
-    del a, b, s1, s2
+    b.data = b.data.clone()                                       # storage moved (`.to()`, dtype change): the entry is REPLACED, not added
+    s3 = ops.weight_stack([a, b])
+    assert s3 is not s2 and len(ops._QKV_CACHE) == n
+    del a, b, s1, s2, s3
     gc.collect()
     c = torch.nn.Parameter(torch.randn(2, 2))
     ops.weight_stack([c, c])                                      # inserting prunes entries whose owner is gone

@@ -473,7 +473,8 @@ def test_winograd_conv3x3_batch_chunking_over_2gib(ops):
 @pytest.mark.parametrize("B,ci,co,H,W,bias,res", [(8, 1280, 1280, 8, 8, True, True), (8, 640, 1280, 16, 16, False, False),
                                                    (8, 2560, 1280, 8, 8, True, False), (2, 256, 64, 16, 16, True, True),
                                                    (3, 320, 128, 8, 12, False, True), (1, 272, 192, 4, 4, True, False),
-                                                   (2, 1280, 1280, 8, 8, True, True)])       # config 3's per-rank rows: 8 tiles of a 32-tile block
+                                                   (2, 1280, 1280, 8, 8, True, True),        # config 3's per-rank rows: 8 tiles -> the one-block form
+                                                   (4, 1280, 1280, 8, 8, False, True), (1, 640, 1280, 16, 16, True, False)])   # exactly 16 tiles
 def test_raw_filter_winograd_small_layers_vs_fp64(ops, B, ci, co, H, W, bias, res):
     """Small-spatial form of the 3x3 convolution (raw taps, G g G^T applied in the lanes, input transform in the workspace:
     skp_conv3x3_f4r_f32) against fp64 conv2d: forward with bias / residual, the input gradient through the same kernel with

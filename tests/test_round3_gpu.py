@@ -5,6 +5,7 @@ refuses head sizes without a kernel; rank-sharding of the augmented inference is
 import numpy as np
 import pytest
 import torch
+from _tol import assert_grad_close
 
 from oracle import ref_path as R
 from oracle.fixtures import LOOP_CASE as lc, seeded
@@ -59,11 +60,11 @@ def tiny(monkeypatch):
 def test_g11_optimize_embedding_trajectory_vs_reference(tiny, golden, images_per_forward):
     """The product's `optimize_embedding` (batched fused steps, HIP kernels, Adam) fed the loader order / noise / thetas
     of the REFERENCE's own `optimize_embedding` run (G11: 3 optimizer steps x 2 accumulated images): the embedding
-    after every optimizer step.  Tolerances: embedding rtol 5e-3 (stated bar) with an absolute floor of a quarter
-    step (lr / 4: values near zero have no relative scale) AND -- because that alone is loose against steps of
-    lr = 5e-3 on unit-scale values -- the DISPLACEMENT from the start embedding: mean error below 2 % of lr, and fewer
-    than 0.5 % of the elements off by more than a quarter step (Adam's first updates are sign(g)*lr, so an element
-    whose accumulated gradient is at rounding level may legitimately move differently)."""
+    after every optimizer step.  Tolerance on the DISPLACEMENT from the start embedding (the embedding itself is unit-scale,
+    the steps are lr = 5e-3): every element within 0.12 lr of the reference's displacement and the mean error below 1e-3 lr --
+    2x what the MI355X shows (round 6: max 0.016 / 0.055 lr for the two groupings, mean < 1e-4 lr).  Adam's first updates are
+    ~sign(g) * lr, so an element whose accumulated gradient sits at rounding level moves by a fraction of lr differently; rounds
+    1-5 allowed a quarter step for 0.5 % of the elements."""
     from stablekeypoints_amd.optimize import optimize_embedding
     ldm, controllers, n, images, ctx0 = tiny
     g = golden("g11_reference_trajectory_tiny.npz")
@@ -74,13 +75,10 @@ def test_g11_optimize_embedding_trajectory_vs_reference(tiny, golden, images_per
     got = torch.cat(traj).cpu()
     assert got.shape == ref.shape and torch.equal(out.cpu()[0], got[-1])
     lr = 5e-3
-    torch.testing.assert_close(got, ref, rtol=5e-3, atol=lr / 4)
     for s in range(lc["steps"]):
         err = ((got[s] - ctx0[0]) - (ref[s] - ctx0[0])).abs()
-        print(f"step {s + 1}: displacement error mean {err.mean().item() / lr:.4f} lr, max {err.max().item() / lr:.3f} lr, "
-              f"elements > lr/4: {(err > lr / 4).float().mean().item():.5f}")
-        assert err.mean().item() < 0.02 * lr
-        assert (err > lr / 4).float().mean().item() < 5e-3
+        print(f"step {s + 1}: displacement error mean {err.mean().item() / lr:.5f} lr, max {err.max().item() / lr:.3f} lr")
+        assert err.mean().item() < 1e-3 * lr and err.max().item() < 0.12 * lr
     assert (got[-1] - ctx0[0]).abs().max().item() > 2.5 * lr
 
 
@@ -161,7 +159,7 @@ def test_gpu_attention_core_refuses_unbuilt_head_size():
     assert out.shape == (1, 16, 48)
 
 
-def test_sd15_full_width_step_vs_oracle():
+def test_sd15_full_width_step_vs_oracle(sd15_cpu):
     """FULL-WIDTH SD-1.5 (859.5 M-parameter UNet + VAE encoder, CPU-drawn weights on both sides), one image at 256^2
     (BASELINE configs[0]'s shape), T = 77, R = 128: the product's fused `group_step` on the MI355X against the oracle's
     reference-order CPU step (`oracle/cpu_path.image_step`: materialised attention, x-upsample + second to_q, stack+mean
@@ -177,7 +175,7 @@ def test_sd15_full_width_step_vs_oracle():
     torch.set_num_threads(min(32, torch.get_num_threads()))
     Rup, T, n_cand, top_k = 128, 77, 25, 10
     ldm, controllers, _ = load_ldm("cuda", "sd15", feature_upsample_res=Rup)
-    cpu, _, _ = load_ldm("cpu", "sd15", feature_upsample_res=Rup)
+    cpu = sd15_cpu
     p_gpu, p_cpu = next(ldm.unet.parameters()), next(cpu.unet.parameters())
     assert torch.equal(p_gpu.detach().cpu(), p_cpu.detach())     # same seeded weights on both sides
     g = torch.Generator().manual_seed(5)
@@ -221,7 +219,7 @@ def test_sd15_full_width_step_vs_oracle():
     assert abs(eq_g.item() - equiv.item()) < 2e-3 * abs(equiv.item())
     gref = c_ref.grad
     print("full-width grad: |g|max", gref.abs().max().item(), "max abs diff", (c_gpu.grad.cpu() - gref).abs().max().item())
-    torch.testing.assert_close(c_gpu.grad.cpu(), gref, rtol=5e-3, atol=5e-5 * gref.abs().max().item())
+    assert_grad_close(c_gpu.grad, gref, "test_round3_gpu.py#1")
 
 
 def _fp64_map_and_grad(S, sides, H, T, R, sel, G):
@@ -486,7 +484,7 @@ def test_step_with_many_tokens_vs_oracle():
     gref = c_ref.grad
     if abs(sh.item() - sh_ref) > 1e-3 * abs(sh_ref) or abs(eq.item() - eq_ref) > 2e-3 * abs(eq_ref):
         pytest.skip("token selection hit a near-tie of the KL ranking on this random model (losses differ): not comparable")
-    torch.testing.assert_close(c_gpu.grad.cpu(), gref, rtol=5e-3, atol=5e-5 * gref.abs().max().item())
+    assert_grad_close(c_gpu.grad, gref, "test_round3_gpu.py#2")
 
 
 def test_epilogue_statistics_survive_a_large_channel_mean(monkeypatch):

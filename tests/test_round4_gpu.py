@@ -13,6 +13,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+from _tol import assert_grad_close
 
 from oracle import ref_path as R
 from oracle.fixtures import KPTS_CASE as kc, LOOP_CASE as lc, seeded
@@ -215,11 +216,10 @@ def test_g11_two_ranks_vs_reference(tmp_path, golden):
     ctx0 = (seeded((1, lc["T"], 768), lc["seed"] + 1) * lc["ctx_gain"])[0]
     lr = 5e-3
     assert got.shape == ref.shape
-    torch.testing.assert_close(got, ref, rtol=5e-3, atol=lr / 4)
-    for s in range(lc["steps"]):
+    for s in range(lc["steps"]):                                 # same bar as test_g11_optimize_embedding_trajectory_vs_reference (observed: 0.035 lr)
         err = ((got[s] - ctx0) - (ref[s] - ctx0)).abs()
-        print(f"2 ranks, step {s + 1}: displacement error mean {err.mean().item() / lr:.4f} lr, max {err.max().item() / lr:.3f} lr")
-        assert err.mean().item() < 0.02 * lr and (err > lr / 4).float().mean().item() < 5e-3
+        print(f"2 ranks, step {s + 1}: displacement error mean {err.mean().item() / lr:.5f} lr, max {err.max().item() / lr:.3f} lr")
+        assert err.mean().item() < 1e-3 * lr and err.max().item() < 0.12 * lr
     assert torch.equal(a["idx"], b["idx"]) and torch.equal(a["idx"], t(golden("g12_reference_best_indices_tiny.npz")["indices"]))
     g13 = golden("g13_reference_keypoints_tiny.npz")
     assert torch.equal(a["src"], b["src"]) and torch.equal(a["src"], t(g13["source_argmax"])) and torch.equal(a["tgt"], t(g13["target"]))
@@ -229,7 +229,7 @@ def test_g11_two_ranks_vs_reference(tmp_path, golden):
 # a whole step at config 2's launch shape
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_img", [4, 1])
-def test_sd15_config2_shape_step_vs_oracle(n_img):
+def test_sd15_config2_shape_step_vs_oracle(n_img, sd15_cpu):
     """n_img = 1 is BASELINE config 3's PER-RANK shape (8 images over 8 ranks: 1 image x 2 views, B = 2 rows -- the K-split
     plans, persistent-walk grids and map launches all change with the row count); n_img = 4:
     BASELINE config 2's LAUNCH SHAPE -- full-width SD-1.5, 512^2, 4 images x 2 views (B = 8 rows), T = 77, R = 128, K = 10 of
@@ -247,7 +247,7 @@ def test_sd15_config2_shape_step_vs_oracle(n_img):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     Rup, T, n_cand, top_k = 128, 77, 25, 10
     ldm, controllers, _ = load_ldm("cuda", "sd15", feature_upsample_res=Rup)
-    cpu, _, _ = load_ldm("cpu", "sd15", feature_upsample_res=Rup)
+    cpu = sd15_cpu
     g = torch.Generator().manual_seed(7)
     images = torch.rand(n_img, 3, 512, 512, generator=g)
     ctx = torch.randn(1, T, 768, generator=g) * 5.0
@@ -270,7 +270,6 @@ def test_sd15_config2_shape_step_vs_oracle(n_img):
         ref_sel.append(sel)
         ref_sharp += sharp.item() / n_img
         ref_equiv += equiv.item() / n_img
-    del cpu
     dev, controller = next(iter(controllers.items()))
     tr = RandomAffineWithInverse()
     with torch.no_grad():
@@ -297,7 +296,7 @@ def test_sd15_config2_shape_step_vs_oracle(n_img):
     assert abs(sh_g.item() - ref_sharp) < 1e-3 * abs(ref_sharp)
     assert abs(eq_g.item() - ref_equiv) < 2e-3 * abs(ref_equiv)
     print("config-2 shape grad: |g|max", gref.abs().max().item(), "max abs diff", (c_gpu.grad.cpu() - gref).abs().max().item())
-    torch.testing.assert_close(c_gpu.grad.cpu(), gref, rtol=5e-3, atol=5e-5 * gref.abs().max().item())
+    assert_grad_close(c_gpu.grad, gref, "test_round4_gpu.py#1")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

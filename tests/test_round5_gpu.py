@@ -275,13 +275,13 @@ def test_batched_context_projections_equal_per_layer_projections(monkeypatch):
         loss, eq, sh = group_step(ldm, images, c, args, controller, tr, denom=n, noise=noise.cuda(), thetas=thetas)
         out.setdefault(mode, []).append((loss.item(), eq.item(), sh.item(), c.grad.clone()))
     plan = ldm.unet._skp_ctx_plan
-    assert 0 < len(plan["used"]) < len(plan["mods"])               # the early exit leaves the last up-block layers out
+    assert 0 < len(plan["used"][True]) < len(plan["mods"])         # the early exit leaves the last up-block layers out
     ref = out[False][0]
     for got in out[True]:                                          # first forward (all layers projected) and second (used ones only)
         assert abs(got[0] - ref[0]) <= 1e-5 * abs(ref[0]) and abs(got[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-9
         torch.testing.assert_close(got[3], ref[3], rtol=1e-4, atol=1e-5 * ref[3].abs().max().item())
     assert not ptp_utils._CTX_KV                                   # nothing of a finished forward stays behind
-    # a FULL forward afterwards: the layers beyond the early exit project for themselves once and join the batch from then on
+    # a FULL forward afterwards has its own record (all layers), and leaves the early-exit record alone
     with torch.no_grad():
         both = torch.cat([images.cuda(), tr(images.cuda(), theta=thetas)])
         cg = ctx.clone().cuda()
@@ -293,9 +293,20 @@ def test_batched_context_projections_equal_per_layer_projections(monkeypatch):
         monkeypatch.setattr(ptp_utils, "CTX_KV_BATCHED", False)
         _, pred_ref = ptp_utils.find_pred_noise(ldm, both, cg, device=dev, noise=noise.cuda(), early_exit=False, controllers=controllers)
         controller.reset()
-    assert len(plan["used"]) == len(plan["mods"])
+    assert len(plan["used"][False]) == len(plan["mods"]) and len(plan["used"][True]) < len(plan["mods"])
     for p_ in outs:
         torch.testing.assert_close(p_, pred_ref, rtol=1e-4, atol=1e-5 * pred_ref.abs().max().item())
+    # a layer whose projection is unfrozen afterwards drops out of the plan (it must project for itself to get its gradient)
+    monkeypatch.setattr(ptp_utils, "CTX_KV_BATCHED", True)
+    victim = plan["mods"][0]
+    victim.to_k.weight.requires_grad_(True)
+    try:
+        with torch.no_grad():
+            ptp_utils.find_pred_noise(ldm, both, cg, device=dev, noise=noise.cuda(), early_exit=True, controllers=controllers)
+            controller.reset()
+        assert victim not in ldm.unet._skp_ctx_plan["mods"] and len(ldm.unet._skp_ctx_plan["mods"]) == len(plan["mods"]) - 1
+    finally:
+        victim.to_k.weight.requires_grad_(False)
 
 
 @pytest.mark.parametrize("N,C,H,W", [(8, 1280, 16, 16), (2, 320, 64, 64), (8, 640, 32, 32)])

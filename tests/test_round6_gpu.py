@@ -1,0 +1,115 @@
+"""Round 6: whole-step coverage of two reference options (`--num_subjects > 1`; `load_ldm`'s default
+`feature_upsample_res=256`) and the kernels added this round."""
+import pytest
+import torch
+from _tol import assert_grad_close
+
+from oracle import ref_path as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_step(cpu, images, ctx, thetas, noise, Rup, n_cand, top_k, sigma, num_subjects=1):
+    """The oracle's reference-order CPU step, image by image (optimize.py:347-425): summed gradient / n, mean losses."""
+    from oracle import cpu_path
+    n = images.shape[0]
+    store = R.OracleStore()
+    cpu_path.register_reference_hook(cpu.unet, store, Rup)
+    gref, sels, sharp_m, equiv_m = torch.zeros_like(ctx), [], 0.0, 0.0
+    for i in range(n):
+        c_ref = ctx.clone().requires_grad_(True)
+        loss, sharp, equiv, sel, _, _ = cpu_path.image_step(cpu, images[i:i + 1], c_ref, store, thetas[i:i + 1], noise[i:i + 1],
+                                                            noise[n + i:n + i + 1], furthest_point_num_samples=n_cand, top_k=top_k,
+                                                            sigma=sigma, num_subjects=num_subjects)
+        loss.backward()
+        gref += c_ref.grad / n
+        sels.append(sel)
+        sharp_m += sharp.item() / n
+        equiv_m += equiv.item() / n
+    return gref, sels, sharp_m, equiv_m
+
+
+def test_group_step_two_subjects_vs_oracle():
+    """`--num_subjects 2` (main.py; eval.py:62-81 `find_k_max_pixels` + `mask_radius`, optimize.py:166-179 sharpening towards the
+    two maxima) through the FUSED training node: `group_step` -> `ops.MapLossesFn` with the batched statistics of all images
+    reshaped per subject (`reshape(ns, n, T)`), against the oracle's per-image reference-order step with num_subjects = 2."""
+    from test_e2e_gpu import _setup
+    from stablekeypoints_amd import ops
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import group_step
+    ldm, controllers, cpu, images, ctx, noise, args = _setup()
+    args.num_subjects = 2
+    n = images.shape[0]
+    dev, controller = next(iter(controllers.items()))
+    thetas = torch.cat([R.affine_matrix(11.0, 0.87, (0.13, -0.21)), R.affine_matrix(-9.0, 0.93, (-0.2, 0.1))])
+    gref, sels, sharp_ref, equiv_ref = _oracle_step(cpu, images, ctx, thetas, noise, 32, 8, 4, args.sigma, num_subjects=2)
+    _, _, sharp_1, _ = _oracle_step(cpu, images, ctx, thetas, noise, 32, 8, 4, args.sigma, num_subjects=1)
+    assert abs(sharp_ref - sharp_1) > 1e-3 * abs(sharp_1), "the two-subject target must differ from the one-subject one on this seed"
+    seen = []
+    real_stats = ops.token_stats
+
+    def spy_stats(M, num_subjects=1, **kw):                       # the fused node's batched statistics: all images in one launch
+        seen.append((int(M.shape[0]), int(num_subjects)))
+        return real_stats(M, num_subjects=num_subjects, **kw)
+    ops.token_stats = spy_stats
+    try:
+        c_gpu = ctx.clone().cuda().requires_grad_(True)
+        tr = RandomAffineWithInverse()
+        loss, eq, sh = group_step(ldm, images, c_gpu, args, controller, tr, denom=n, noise=noise.cuda(), thetas=thetas)
+    finally:
+        ops.token_stats = real_stats
+    T = ctx.shape[1]
+    assert (n * T, 2) in seen, seen                                 # ns = 2 went through the batched route of ops.MapLossesFn
+    # the selection with two subjects, image by image on the same maps (optimize.image_losses: the per-image form of the node)
+    from stablekeypoints_amd import ptp_utils
+    from stablekeypoints_amd._maps import collect_maps_batched
+    from stablekeypoints_amd.optimize import image_losses
+    with torch.no_grad():
+        both = torch.cat([images.cuda(), tr(images.cuda(), theta=thetas)])
+        ptp_utils.find_pred_noise(ldm, both, ctx.cuda(), device=dev, noise=noise.cuda(), early_exit=True, controllers=controllers)
+        maps = collect_maps_batched(controller)
+    for i in range(n):
+        _, _, sel_g = image_losses(maps[i], maps[n + i], thetas[i].reshape(-1).tolist(), args)
+        assert torch.equal(sel_g.cpu(), sels[i]), f"image {i}: selected tokens differ from the reference's"
+    assert abs(sh.item() - sharp_ref) < 1e-3 * abs(sharp_ref)
+    assert abs(eq.item() - equiv_ref) < 2e-3 * abs(equiv_ref)
+    assert_grad_close(c_gpu.grad, gref, "two subjects, tiny tree")
+
+
+def test_sd15_step_at_load_ldm_default_res_256_vs_oracle(sd15_cpu):
+    """One full-width SD-1.5 step at `feature_upsample_res=256` -- `load_ldm`'s own default (optimize_token.py:24) -- 512^2,
+    one image x 2 views, T = 77, K = 10 of 25: hooked layers 16^2 x 3 + 32^2 up-sampled 16x / 8x (the column-sweep map backward
+    serves 4x / 8x only, so this step runs the general dense-gradient route and R = 256 tiles of the forward) against the
+    oracle's reference-order CPU step."""
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import default_args, group_step
+    from stablekeypoints_amd.optimize_token import load_ldm
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    Rup, T, n_cand, top_k = 256, 77, 25, 10
+    ldm, controllers, _ = load_ldm("cuda", "sd15")                       # feature_upsample_res left at its default
+    dev, controller = next(iter(controllers.items()))
+    cpu = sd15_cpu
+    g = torch.Generator().manual_seed(11)
+    images = torch.rand(1, 3, 512, 512, generator=g)
+    ctx = torch.randn(1, T, 768, generator=g) * 5.0
+    noise = torch.randn(2, 4, 64, 64, generator=g)
+    thetas = R.affine_matrix(-8.0, 0.9, (0.12, -0.1))
+    args = default_args(num_tokens=T, feature_upsample_res=Rup, furthest_point_num_samples=n_cand, top_k=top_k, batch_size=1)
+    gref, sels, sharp_ref, equiv_ref = _oracle_step(cpu, images, ctx, thetas, noise, Rup, n_cand, top_k, args.sigma)
+    c_gpu = ctx.clone().cuda().requires_grad_(True)
+    from stablekeypoints_amd import ops
+    seen = []
+    real = ops._map_fwd
+
+    def spy(S, sides, B, H, T_, R_, *a, **k):
+        seen.append((tuple(sides), R_))
+        return real(S, sides, B, H, T_, R_, *a, **k)
+    ops._map_fwd = spy
+    try:
+        loss, eq, sh = group_step(ldm, images, c_gpu, args, controller, RandomAffineWithInverse(), denom=1, noise=noise.cuda(), thetas=thetas)
+    finally:
+        ops._map_fwd = real
+    assert seen == [((16, 16, 16, 32), 256)], seen
+    assert abs(sh.item() - sharp_ref) < 1e-3 * abs(sharp_ref)
+    assert abs(eq.item() - equiv_ref) < 2e-3 * abs(equiv_ref)
+    assert_grad_close(c_gpu.grad, gref, "sd15 512^2, R = 256 (load_ldm default)")
