@@ -412,6 +412,40 @@ def cpu_baseline(ldm_cpu, args):
             "thread_sweep_256_images_per_sec": {str(k): v for k, v in sweep.items()}}
 
 
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9     # fp32 VALU issue: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz (a wave instruction = 4 clk;
+                                                # packed fp32 is half rate on this part, profiles/r02_mfma_valu_probe.md: no second factor)
+
+
+def map_valu_roof(B, L, H, T, R, fwd_s):
+    """The roof that BINDS the fused map forward: VALU issue.  Per (layer, head, token, up-res pixel) element the kernel
+    (csrc/skp_attn_map.hip, skp_attn_map_fwd_kernel, quad layers) issues, in lane-clocks: horizontal bicubic 1 mul + 3 DPP fmacs
+    = 4; running max 1; subtract the max 1 (packed: two tokens per instruction at half rate); exp2 4 (quarter-rate
+    transcendental); row sum 1; normalise + accumulate 1 = 12.  Pad tokens (NT = 16 ceil(T / 16)) are computed too.  The V phase
+    (vertical taps into LDS, shared by the 4..8 pixels under a low-res row) and the stores add ~5 %, not modelled."""
+    nt = (T + 15) // 16 * 16
+    elements = float(B) * L * H * nt * R * R
+    ops = {"horizontal bicubic (mul + 3 DPP fmac)": 4, "running max": 1, "subtract max": 1, "exp2 (quarter rate)": 4, "row sum": 1,
+           "normalise + accumulate": 1}
+    per = sum(ops.values())
+    floor = elements * per / VALU_LANE_OPS_PER_S
+    counted = None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_map*.json")), reverse=True):
+        try:
+            for name, c in json.load(open(path))["kernels"].items():
+                if "skp_attn_map_fwd_kernel" in name and "SQ_INSTS_VALU" in c:
+                    counted = {"source": "profiles/" + os.path.basename(path), "SQ_INSTS_VALU_per_launch": c["SQ_INSTS_VALU"],
+                               "issue_floor_us": c["SQ_INSTS_VALU"] * 4 / (256 * 4) / 2.4e9 * 1e6,
+                               **{k: c[k] for k in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES") if k in c}}
+                    break
+        except Exception:
+            continue
+        if counted:
+            break
+    return {"bound": "valu", "elements": elements, "lane_clocks_per_element": per, "model": ops, "peak_lane_ops_per_s": VALU_LANE_OPS_PER_S,
+            "floor_us": floor * 1e6, "launch_us": fwd_s * 1e6, "frac": floor / fwd_s, "counters": counted}
+
+
 def measured_traffic(kernel_substr, template=None):
     """(HBM bytes per launch, source file) of a kernel from the committed rocprofv3 --pmc passes (profiles/*.json: separate
     FETCH_SIZE / WRITE_SIZE runs of tools/kbench.py at the same launch shape, FETCH_SIZE doubled per
@@ -807,6 +841,11 @@ def main():
                          "bwd_launch_us": kt["bwd"] * 1e6, "bwd_achieved": bwd_bytes / kt["bwd"] / 1e9,
                          "bwd_frac": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS, "bwd_algorithmic_bytes": bwd_bytes,
                          "bwd_traffic": map_bwd_traffic,
+                         "valu": (map_valu_roof(B, len(ldims or [0] * 4), (ldims or [(16, 1280, 8)])[0][2], a.tokens, a.res, kt["fwd"])
+                                  if a.tokens <= 128 else None),
+                         "bound_note": "the HBM fraction above is the contract's figure; the kernel is VALU-issue bound by design (the "
+                                       "logits are up-sampled instead of the activations: 1.01x algorithmic traffic) -- `valu` prices it "
+                                       "against the roof that binds it",
                          "reference_contraction_equiv_tflops": flops_equiv / kt["fwd"] / 1e12,
                          "f32_matrix_peak_tflops": F32_MATRIX_PEAK_TF},
             "roofline_self_attn": {"kernel": "flash self-attention forward, 64^2 layers (N=4096, 8 heads x 40)",

@@ -37,13 +37,15 @@ def test_group_step_two_subjects_vs_oracle():
     from stablekeypoints_amd import ops
     from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
     from stablekeypoints_amd.optimize import group_step
-    ldm, controllers, cpu, images, ctx, noise, args = _setup()
+    # 512^2 images on the reduced-width tree: hooked layers 16^2 x 3 + 32^2 at R = 128, the shapes whose step takes the fused node
+    # (ops.map_bwd_sparse_supported: column-sweep backward) -- at the tiny default (R = 32) the step runs image by image
+    ldm, controllers, cpu, images, ctx, noise, args = _setup(R_up=128, T=16, n=2, size=512)
     args.num_subjects = 2
     n = images.shape[0]
     dev, controller = next(iter(controllers.items()))
     thetas = torch.cat([R.affine_matrix(11.0, 0.87, (0.13, -0.21)), R.affine_matrix(-9.0, 0.93, (-0.2, 0.1))])
-    gref, sels, sharp_ref, equiv_ref = _oracle_step(cpu, images, ctx, thetas, noise, 32, 8, 4, args.sigma, num_subjects=2)
-    _, _, sharp_1, _ = _oracle_step(cpu, images, ctx, thetas, noise, 32, 8, 4, args.sigma, num_subjects=1)
+    gref, sels, sharp_ref, equiv_ref = _oracle_step(cpu, images, ctx, thetas, noise, 128, 8, 4, args.sigma, num_subjects=2)
+    _, _, sharp_1, _ = _oracle_step(cpu, images, ctx, thetas, noise, 128, 8, 4, args.sigma, num_subjects=1)
     assert abs(sharp_ref - sharp_1) > 1e-3 * abs(sharp_1), "the two-subject target must differ from the one-subject one on this seed"
     seen = []
     real_stats = ops.token_stats
