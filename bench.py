@@ -34,8 +34,11 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+DTYPE_LINE = ("f32 (fp32 MFMA / VALU throughout; flash attention of the >= 1024-key self-attention layers: 3xbf16 operand split, "
+              "fp32 accumulate, error <= the fp32 kernel's)")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 F32_MATRIX_PEAK_TF = 157.3     # fp32 MFMA == fp32 vector peak
+BF16_MATRIX_PEAK_TF = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md; the 5 PF/s headline is 2:1 sparsity)
 
 
 def parse():
@@ -71,7 +74,7 @@ def parse():
     ap.add_argument("--verify", default="auto", choices=["auto", "on", "off"],
                     help="host-drawn weights on BOTH legs and one 256^2 image through the oracle's reference-order CPU step and the "
                          "MI355X step: loss / gradient agreement goes into the line (auto: with the CPU baseline leg)")
-    ap.add_argument("--f32-split", default="auto", choices=["auto", "off"],
+    ap.add_argument("--f32-split", "--f32-instr", dest="f32_split", default="auto", choices=["auto", "off"],
                     help="auto: after the timed steps, time the same step with the split-bf16 flash-attention kernels (the "
                          "`f32_split` key; sd* models at N = 1); off: skip it (profiling runs that window on the last steps)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
@@ -722,14 +725,13 @@ def main():
         sa, sa_f, sa_b = self_attn_roofline(ops, B, max(10, a.kernel_iters // 3), dev)
         cv_t, cv_direct, cv_bytes, cv_grid, cv_rows, cv_folded = conv_roofline(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
         cv_forms = conv_step_forms(ops, B, min(image_size, 512), max(10, a.kernel_iters // 3), dev)
-        f32_split = None
+        f32_instr = None
         if a.model.startswith("sd") and world == 1 and a.f32_split != "off":
-            # EXPERIMENT beside the line of record (never part of `value`): fp32-accurate matrix products on the bf16 matrix
-            # cores by three-term operand splits.  (1) the step with the flash-attention forward routed through the split kernel
-            # (the one kernel family where the split pays), timed like the line of record; (2) the two split kernels next to
-            # their fp32-instruction counterparts on this box.
+            # Beside the line of record (never part of `value`): the same step with the flash attention of the 64^2 / 32^2
+            # self-attention layers on the fp32-INSTRUCTION kernels (rounds 1-5's route; the line runs them on the bf16 matrix cores
+            # with three-term operand splits, fp32 accumulate), and the two forward kernels side by side with their errors vs fp64.
             try:
-                ops.FLASH_SPLIT = True
+                ops.FLASH_SPLIT = False
                 for _ in range(2):
                     one_step()
                 torch.cuda.synchronize()
@@ -738,20 +740,19 @@ def main():
                     one_step()
                 torch.cuda.synchronize()
                 el_s = time.perf_counter() - t0s
-                ops.FLASH_SPLIT = False
+                ops.FLASH_SPLIT = True
                 fa_probe = split_flash_probe(ops, B, max(5, a.kernel_iters // 6), dev)
-                f32_split = {"value": global_batch * a.steps / el_s, "ms_per_step": el_s / a.steps * 1e3, "unit": "images/sec",
-                             "dtype": "f32 via 3 x bf16 operand split (6 products), fp32 accumulate",
-                             "what": "the same step with the self-attention of the 64^2 / 32^2 layers on the split kernels "
-                                     "(SKP_FLASH_SPLIT=1: forward at d = 40 / 80, backward at d = 40); everything else, incl. the "
-                                     "convolutions, on the fp32 instructions",
-                             "max_err_vs_fp64_ratio": fa_probe["max_err_vs_fp64_ratio"],
-                             "flash_forward": fa_probe,
-                             "on_path_of_record": False}
-            except Exception as e:                                # noqa: BLE001 -- an experiment key never takes the line of record down
-                ops.FLASH_SPLIT = False
-                print(f"bench.py: f32_split experiment unavailable ({e})", file=sys.stderr)
-                f32_split = None
+                f32_instr = {"value": global_batch * a.steps / el_s, "ms_per_step": el_s / a.steps * 1e3, "unit": "images/sec",
+                             "dtype": "f32 (v_mfma_f32_16x16x4_f32 in every matrix kernel)",
+                             "what": "the same step with ops.FLASH_SPLIT = False: self-attention of the 64^2 / 32^2 layers on the "
+                                     "fp32-instruction flash kernels (forward at d = 40 / 80, backward at d = 40 are the launches that differ)",
+                             "split_max_err_vs_fp64_over_fp32_kernel": fa_probe["max_err_vs_fp64_ratio"],
+                             "flash_forward": fa_probe}
+            except Exception as e:                                # noqa: BLE001 -- a comparison key never takes the line of record down
+                print(f"bench.py: f32_instr comparison unavailable ({e})", file=sys.stderr)
+                f32_instr = None
+            finally:
+                ops.FLASH_SPLIT = True
         def local_step():                                        # rank 0 only: the step without its collective
             nonlocal cursor
             idx = [(cursor + i) % len(data) for i in range(per_rank)]
@@ -801,7 +802,7 @@ def main():
                                    "strong: the global batch is fixed (global_batch images per optimizer step), each rank "
                                    "processes global_batch / N of them"),
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE_LINE,
             "data": "synthetic",
             **({"experiment": "cache_latents: the un-warped views' latents are reused from the first epoch over the "
                               f"{len(data)}-image synthetic set (half of each step's VAE work skipped); NOT the bench of record"}
@@ -848,13 +849,19 @@ def main():
                                        "against the roof that binds it",
                          "reference_contraction_equiv_tflops": flops_equiv / kt["fwd"] / 1e12,
                          "f32_matrix_peak_tflops": F32_MATRIX_PEAK_TF},
-            "roofline_self_attn": {"kernel": "flash self-attention forward, 64^2 layers (N=4096, 8 heads x 40)",
-                                   "bound": "mfma", "achieved": sa_f / sa["fwd"] / 1e12, "peak": F32_MATRIX_PEAK_TF,
-                                   "unit": "TFLOP/s", "frac": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
+            # flash self-attention of the 64^2 layers: bf16 matrix cores, every fp32 product = 6 bf16 products (three-term splits);
+            # forward 2 tile products, backward (two kernels) 7 -- executed bf16 FLOPs against the dense bf16 peak, and the
+            # fp32-equivalent rate (algorithmic FLOPs / time) next to the fp32 matrix peak it replaces
+            "roofline_self_attn": {"kernel": "skp_fas_fwd_kernel<40> (+ K/V split pre-pass): flash self-attention forward, 64^2 layers "
+                                             "(N=4096, 8 heads x 40), v_mfma_f32_16x16x32_bf16 on 3-term operand splits",
+                                   "bound": "mfma", "achieved": 6 * sa_f / sa["fwd"] / 1e12, "peak": BF16_MATRIX_PEAK_TF,
+                                   "unit": "TFLOP/s", "frac": 6 * sa_f / sa["fwd"] / 1e12 / BF16_MATRIX_PEAK_TF,
+                                   "fp32_equiv_tflops": sa_f / sa["fwd"] / 1e12, "fp32_matrix_peak_tflops": F32_MATRIX_PEAK_TF,
                                    "traffic": None, "launch_us": sa["fwd"] * 1e6, "algorithmic_flops": sa_f,
-                                   "bwd_us": sa["bwd"] * 1e6, "bwd_achieved": sa_b / sa["bwd"] / 1e12,
-                                   "bwd_frac": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF,
-                                   "rows_per_launch": B, "dtype": "f32 MFMA"},
+                                   "bwd_us": sa["bwd"] * 1e6, "bwd_fp32_equiv_tflops": sa_b / sa["bwd"] / 1e12,
+                                   "bwd_executed_tflops": 6 * (7.0 / 5.0) * sa_b / sa["bwd"] / 1e12,
+                                   "bwd_frac": 6 * (7.0 / 5.0) * sa_b / sa["bwd"] / 1e12 / BF16_MATRIX_PEAK_TF,
+                                   "rows_per_launch": B, "dtype": "f32 in/out/accumulate; products on bf16 MFMA, 3 x bf16 terms per operand"},
             # what the matrix pipe sustains on THIS box for back-to-back independent fp32 MFMAs (no loads, no VALU work):
             # the practical ceiling under the nominal peak the fractions above are quoted against
             "mfma_issue_ceiling": {"unit": "TFLOP/s", "nominal_peak": F32_MATRIX_PEAK_TF,
@@ -862,9 +869,9 @@ def main():
                                    "note": "skp_probe_mfma_f32; the Winograd conv kernels hold one wave per SIMD "
                                            "(288 accumulators), the attention kernels two"},
             "attention_roofline_frac": {"map_fwd_hbm": ach / HBM_PEAK_GBS, "map_bwd_hbm": bwd_bytes / kt["bwd"] / 1e9 / HBM_PEAK_GBS,
-                                        "self_attn_fwd_mfma": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
-                                        "self_attn_bwd_mfma": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF},
-            "f32_split": f32_split,
+                                        "self_attn_fwd_fp32_equiv_over_fp32_peak": sa_f / sa["fwd"] / 1e12 / F32_MATRIX_PEAK_TF,
+                                        "self_attn_bwd_fp32_equiv_over_fp32_peak": sa_b / sa["bwd"] / 1e12 / F32_MATRIX_PEAK_TF},
+            "f32_instr": f32_instr,
             "traffic_live_kernels": sorted(live) if live else None,
             "cpu_baseline": cpu_stats, "verify": verify, "collective_check": coll,
             "loss": float(last[0]), "setup_s": t_build, "cpu_baseline_s": t_cpu,

@@ -243,6 +243,10 @@ int64_t skp_flash_attn_bwd_split_workspace(int B, int Bk, int H, int N, int Nk, 
 int skp_flash_attn_bwd_split_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
                                  const float* lse, float* dq, float* dk, float* dv, void* workspace, int B, int Bk, int H, int N,
                                  int Nk, int d, float scale, void* stream);
+/* ... with dq, dk, dv as column bands of wider buffers (row stride ldg floats), as skp_flash_attn_bwd_ld_f32 */
+int skp_flash_attn_bwd_split_ld_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                    const float* lse, float* dq, float* dk, float* dv, void* workspace, int B, int Bk, int H,
+                                    int N, int Nk, int d, float scale, int ldg, void* stream);
 
 /* Flash-style self-attention (ptp_utils.py:493-506 with context = x) for the long image-token sequences: fp32 MFMA,
  * 64-key tiles in LDS, online softmax; the [B*h,N,N] scores are never materialised.

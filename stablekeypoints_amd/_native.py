@@ -74,6 +74,7 @@ SIGNATURES = {
     "skp_flash_attn_bwd_split_ok": [_i, _i, _i, _i, _i, _i],
     "skp_flash_attn_bwd_split_workspace": [_i, _i, _i, _i, _i, _i],
     "skp_flash_attn_bwd_split_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "skp_flash_attn_bwd_split_ld_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "skp_conv3x3_f4r_ok": [_i, _i, _i, _i, _i],
     "skp_conv3x3_f4r_filter_f32": [_vp, _vp, _i, _i, _i, _vp],
     "skp_conv3x3_f4r_workspace": [_i, _i, _i, _i, _i],

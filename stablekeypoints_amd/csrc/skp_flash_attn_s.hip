@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void skp_fas_bwd_dq_kernel(const float* __r
                                                                const float* __restrict__ lse, const float* __restrict__ Kr,
                                                                const float* __restrict__ Vr, const float* __restrict__ Kt,
                                                                float* __restrict__ dq, float* __restrict__ Dn, int H, int N, int Nk,
-                                                               int ntiles, float scale) {
+                                                               int ntiles, float scale, int ldg) {
     using F = FAS<D>;
     constexpr int NQT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2 buffers][K | V | K^T images]
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void skp_fas_bwd_dq_kernel(const float* __r
     for (int nt = 0; nt < NQT; ++nt) {
         const int n = nrow[nt];
         if (n < N) {
-            float* drow = dq + ((size_t)b * N + n) * C + h * D;
+            float* drow = dq + ((size_t)b * N + n) * ldg + h * D;
 #pragma unroll
             for (int ct = 0; ct < F::G; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void skp_fas_bwd_dkv_kernel(const float* __
                                                                 const float* __restrict__ Dn, const float* __restrict__ Qr,
                                                                 const float* __restrict__ Gr, const float* __restrict__ Qt,
                                                                 const float* __restrict__ Gt, float* __restrict__ dk, float* __restrict__ dv,
-                                                                int H, int N, int Nk, int nqtiles, float scale) {
+                                                                int H, int N, int Nk, int nqtiles, float scale, int ldg) {
     using F = FAS<D>;
     constexpr int NKB = 2, NB = 2;                              // 16-key blocks per wave, 16-query blocks per tile
     constexpr int QMAT = NB * F::G * 2 * 1024;                  // bytes of one query-tile image
@@ -539,8 +539,8 @@ __global__ __launch_bounds__(512, 2) void skp_fas_bwd_dkv_kernel(const float* __
     for (int kb = 0; kb < NKB; ++kb) {
         const int t = trow[kb];
         if (t < Nk) {
-            float* krow = dk + ((size_t)b * Nk + t) * C + h * D;
-            float* vrow = dv + ((size_t)b * Nk + t) * C + h * D;
+            float* krow = dk + ((size_t)b * Nk + t) * ldg + h * D;
+            float* vrow = dv + ((size_t)b * Nk + t) * ldg + h * D;
 #pragma unroll
             for (int ct = 0; ct < F::G; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void skp_fas_bwd_dkv_kernel(const float* __
 
 template <int D>
 static int fas_bwd_run(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse, float* dq,
-                       float* dk, float* dv, void* workspace, int B, int H, int N, float scale, hipStream_t st) {
+                       float* dk, float* dv, void* workspace, int B, int H, int N, float scale, int ldg, hipStream_t st) {
     using F = FAS<D>;
     const int ntiles = (N + F::KT - 1) / F::KT, nqtiles = (N + 31) / 32;
     const size_t kimg = (size_t)B * H * ntiles * F::MAT_B;                  // 64-row tiles: K, V (row), K^T
@@ -580,9 +580,9 @@ static int fas_bwd_run(const float* q, const float* k, const float* v, const flo
         attr_set = true;
     }
     hipLaunchKernelGGL(skp_fas_bwd_dq_kernel<D>, dim3((N + 255) / 256, H, B), dim3(512), lds_q, st, q, o, dout, lse, (const float*)Kr,
-                       (const float*)Vr, (const float*)Kt, dq, Dn, H, N, N, ntiles, scale);
+                       (const float*)Vr, (const float*)Kt, dq, Dn, H, N, N, ntiles, scale, ldg);
     hipLaunchKernelGGL(skp_fas_bwd_dkv_kernel<D>, dim3((N + 255) / 256, H, B), dim3(512), lds_k, st, k, v, lse, (const float*)Dn,
-                       (const float*)Qr, (const float*)Gr, (const float*)Qt, (const float*)Gt, dk, dv, H, N, N, nqtiles, scale);
+                       (const float*)Qr, (const float*)Gr, (const float*)Qt, (const float*)Gt, dk, dv, H, N, N, nqtiles, scale, ldg);
     return skp_launch_status();
 }
 
@@ -655,5 +655,15 @@ extern "C" int skp_flash_attn_bwd_split_f32(const float* q, const float* k, cons
                                             int N, int Nk, int d, float scale, void* stream) {
     if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return SKP_E_BADARG;
     if (!skp_flash_attn_bwd_split_ok(B, Bk, H, N, Nk, d)) return SKP_E_RANGE;
-    return fas_bwd_run<40>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, scale, (hipStream_t)stream);
+    return fas_bwd_run<40>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, scale, H * d, (hipStream_t)stream);
+}
+// the same with dq, dk, dv as column bands of wider row-major buffers (row stride ldg floats >= H * d, multiple of 4): see
+// skp_flash_attn_bwd_ld_f32
+extern "C" int skp_flash_attn_bwd_split_ld_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                               const float* lse, float* dq, float* dk, float* dv, void* workspace, int B, int Bk, int H,
+                                               int N, int Nk, int d, float scale, int ldg, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !workspace) return SKP_E_BADARG;
+    if (ldg < H * d || (ldg & 3)) return SKP_E_BADARG;
+    if (!skp_flash_attn_bwd_split_ok(B, Bk, H, N, Nk, d)) return SKP_E_RANGE;
+    return fas_bwd_run<40>(q, k, v, out, dout, lse, dq, dk, dv, workspace, B, H, N, scale, ldg, (hipStream_t)stream);
 }

@@ -701,13 +701,14 @@ def self_attn_supported(C: int, heads: int) -> bool:
     return C % heads == 0 and (C // heads) in CROSS_ATTN_HEAD_DIMS
 
 
-# EXPERIMENT (opt-in, never the path of record): the flash-attention FORWARD on the bf16 matrix cores with three-term operand
-# splits (csrc/skp_flash_attn_s.hip; same out / lse contract, the fp32 backward kernels run on its lse).  SKP_FLASH_SPLIT=1
-# routes the layers it serves (d = 40 / 80, >= 1024 keys) through it; bench.py reports that step as `f32_split`.
-FLASH_SPLIT = False
+# Flash attention of the big self-attention layers (>= 1024 keys, d = 40 / 80: the 64^2 and 32^2 levels) runs on the BF16 matrix
+# cores with THREE-TERM OPERAND SPLITS (csrc/skp_flash_attn_s.hip): fp32 in / out, fp32 softmax and accumulation, every operand of the
+# tile products the exact sum of three bf16 terms, six products per fp32 product.  Error against fp64 0.16-0.87x the
+# fp32-instruction kernels' on the shapes it serves (tests/test_round5_gpu.py), forward 1.43-1.87x their speed, backward (d = 40)
+# 1.10x (profiles/r05_flash_split.md).  Round 6 made it the route of record; FLASH_SPLIT = False restores the fp32-instruction
+# kernels everywhere (bench.py times that step beside the line as `f32_instr`).
+FLASH_SPLIT = True
 FLASH_SPLIT_MIN_KEYS = 1024
-
-
 def flash_split_ok(B, Bk, heads, Nq, Nk, d) -> bool:
     return Nk >= FLASH_SPLIT_MIN_KEYS and bool(N.lib().skp_flash_attn_fwd_split_ok(B, Bk, heads, Nq, Nk, d))
 
@@ -1302,8 +1303,11 @@ class SelfAttnQKVFn(torch.autograd.Function):
         B, Nq, C = q.shape
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, Nq, device=q.device, dtype=torch.float32)
-        N.check(N.lib().skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                                               B, B, heads, Nq, Nq, C // heads, float(scale), _stream()), "skp_flash_attn_fwd_f32")
+        if FLASH_SPLIT and flash_split_ok(B, B, heads, Nq, Nq, C // heads):
+            _flash_fwd_split(q, k, v, out, lse, heads, float(scale))
+        else:
+            N.check(N.lib().skp_flash_attn_fwd_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                   B, B, heads, Nq, Nq, C // heads, float(scale), _stream()), "skp_flash_attn_fwd_f32")
         ctx.save_for_backward(q, k, v, out, lse, wq, wk, wv)
         ctx.meta = (int(heads), float(scale), tuple(x.shape))
         return out
@@ -1315,11 +1319,19 @@ class SelfAttnQKVFn(torch.autograd.Function):
         dout = _dev(dout, "dout")
         B, Nq, C = q.shape
         d3 = torch.empty(B * Nq, 3 * C, device=q.device, dtype=torch.float32)
+        p = d3.data_ptr()
+        if FLASH_SPLIT and Nq >= FLASH_SPLIT_MIN_KEYS and N.lib().skp_flash_attn_bwd_split_ok(B, B, heads, Nq, Nq, C // heads):
+            nbytes = N.lib().skp_flash_attn_bwd_split_workspace(B, B, heads, Nq, Nq, C // heads)
+            ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
+            N.check(N.lib().skp_flash_attn_bwd_split_ld_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                                            lse.data_ptr(), p, p + 4 * C, p + 8 * C, ws.data_ptr(), B, B, heads, Nq, Nq,
+                                                            C // heads, scale, 3 * C, _stream()), "skp_flash_attn_bwd_split_ld_f32")
+            dx = torch.mm(d3, _qkv_stack(wq, wk, wv).view(3 * C, wq.shape[1]))
+            return dx.view(xshape), None, None, None, None, None
         nbytes = N.lib().skp_flash_attn_bwd_workspace(B, B, heads, Nq, Nq, C // heads)
         if nbytes < 0:
             N.check(int(nbytes), "skp_flash_attn_bwd_workspace")
         ws = torch.empty(nbytes // 4, device=q.device, dtype=torch.float32)
-        p = d3.data_ptr()
         N.check(N.lib().skp_flash_attn_bwd_ld_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                                   lse.data_ptr(), p, p + 4 * C, p + 8 * C, ws.data_ptr(), B, B, heads, Nq, Nq,
                                                   C // heads, scale, 3 * C, _stream()), "skp_flash_attn_bwd_ld_f32")
@@ -1333,9 +1345,9 @@ FA2_HEAD_DIMS = (40, 64, 80, 160)          # head sizes of the second-generation
 def self_attention_block(x, wq, wk, wv, heads: int, scale: float):
     """Self-attention core of a block whose q / k / v projections are frozen and bias-free: projections + attention, with
     the fused input gradient where the kernels serve the head size; the composition of `qkv_proj` and `self_attention`
-    otherwise (no gradient wanted, split-bf16 experiment switched on, other head sizes)."""
+    otherwise (no gradient wanted, other head sizes)."""
     frozen = not (wq.requires_grad or wk.requires_grad or wv.requires_grad)
-    if (QKV_STACKED and QKV_ACCUM and not FLASH_SPLIT and x.is_cuda and x.dim() == 3 and frozen and x.requires_grad
+    if (QKV_STACKED and QKV_ACCUM and x.is_cuda and x.dim() == 3 and frozen and x.requires_grad
             and torch.is_grad_enabled() and wq.shape == wk.shape == wv.shape and wq.shape[0] % heads == 0
             and (wq.shape[0] // heads) in FA2_HEAD_DIMS):
         return SelfAttnQKVFn.apply(_dev(x, "x"), wq, wk, wv, int(heads), float(scale))

@@ -190,12 +190,15 @@ def test_split_bf16_flash_attention_backward_vs_fp64(B, H, N):
     assert torch.equal(qa.grad, dq) and torch.equal(ka.grad, dk) and torch.equal(va.grad, dv)
 
 
-@pytest.mark.parametrize("B,H,N,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (3, 8, 256, 160), (1, 8, 64, 160), (1, 3, 300, 40)])
-def test_self_attention_block_stacked_projections_vs_fp64(B, H, N, d):
+@pytest.mark.parametrize("B,H,N,d,split", [(2, 8, 1024, 40, True), (2, 8, 1024, 40, False), (2, 8, 1024, 80, True), (2, 8, 256, 80, True),
+                                           (3, 8, 256, 160, True), (1, 8, 64, 160, True), (1, 3, 300, 40, True)])
+def test_self_attention_block_stacked_projections_vs_fp64(B, H, N, d, split, monkeypatch):
     """q | k | v as one batched GEMM + the flash backward writing dq | dk | dv as column bands of one [B*N, 3C] buffer
-    (skp_flash_attn_bwd_ld_f32) + ONE input-gradient GEMM: output and dx against an fp64 reference of the block
-    (ptp_utils.py:513-520, 493-506) and against the three-projection composition it replaces."""
+    (skp_flash_attn_bwd_ld_f32; at >= 1024 keys and d = 40 its split-bf16 form skp_flash_attn_bwd_split_ld_f32, the route of
+    record since round 6; `split` False: the fp32-instruction kernels at the same shape) + ONE input-gradient GEMM: output and dx
+    against an fp64 reference of the block (ptp_utils.py:513-520, 493-506) and against the three-projection composition it replaces."""
     from stablekeypoints_amd import ops
+    monkeypatch.setattr(ops, "FLASH_SPLIT", split)
     g = torch.Generator().manual_seed(5)
     C = H * d
     x64 = torch.randn(B, N, C, generator=g, dtype=torch.float64)
