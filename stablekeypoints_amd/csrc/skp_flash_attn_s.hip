@@ -632,9 +632,13 @@ extern "C" int skp_flash_attn_fwd_split_f32(const float* q, const float* k, cons
     if (B <= 0 || H <= 0 || N <= 0 || Nk <= 0 || (Bk != 1 && Bk != B)) return SKP_E_BADARG;
     if (!skp_flash_attn_fwd_split_ok(B, Bk, H, N, Nk, d)) return SKP_E_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    // (64 queries per wave measured no faster at d = 40 and spills: 32 it is)
-    if (d == 40) return fas_run<40, 2>(q, k, v, out, lse, workspace, B, Bk, H, N, Nk, scale, st);
-    return fas_run<80, 2>(q, k, v, out, lse, workspace, B, Bk, H, N, Nk, scale, st);
+    // (64 queries per wave measured no faster at d = 40 and spills: 32 it is); 16 per wave where 32 would leave CUs without a
+    // workgroup (the 32^2 layers of a 1- or 2-image step: 64 workgroups of 256 queries)
+    const bool small = (long)((N + 255) / 256) * H * B < 256;
+    if (d == 40) return small ? fas_run<40, 1>(q, k, v, out, lse, workspace, B, Bk, H, N, Nk, scale, st)
+                              : fas_run<40, 2>(q, k, v, out, lse, workspace, B, Bk, H, N, Nk, scale, st);
+    return small ? fas_run<80, 1>(q, k, v, out, lse, workspace, B, Bk, H, N, Nk, scale, st)
+                 : fas_run<80, 2>(q, k, v, out, lse, workspace, B, Bk, H, N, Nk, scale, st);
 }
 
 // ---- backward (self-attention: Bk == B, Nk == N), d = 40 ----
