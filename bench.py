@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--f32-split", "--f32-instr", dest="f32_split", default="auto", choices=["auto", "off"],
                     help="auto: after the timed steps, time the same step with the split-bf16 flash-attention kernels (the "
                          "`f32_split` key; sd* models at N = 1); off: skip it (profiling runs that window on the last steps)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="the step as a captured hipGraph (optimize.GraphedStep): auto = the product's rule (<= 2 images per rank)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
     ap.add_argument("--channels-last", action="store_true")
     return ap.parse_args()
@@ -677,12 +679,21 @@ def main():
     cursor = 0
     latent_cache = {} if a.cache_latents else None
 
-    def one_step():
+    # small per-rank batches are launch-bound on the host: the product captures their step in a hipGraph (optimize.GraphedStep,
+    # `capture_step="auto"` = groups of <= 2 images); the bench follows the product's rule unless told otherwise
+    from stablekeypoints_amd.optimize import GraphedStep
+    use_graph = latent_cache is None and (a.graph == "on" or (a.graph == "auto" and per_rank <= 2))
+    graphed = GraphedStep(ldm, ctx, args, controller, transform, global_batch, warn_route=(a.graph == "on")) if use_graph else None
+
+    def one_step(eager=False):
         nonlocal cursor
         idx = [(cursor + i) % len(data) for i in range(per_rank)]
         cursor += per_rank
         images = torch.stack([data[i]["img"] for i in idx])
-        out = group_step(ldm, images, ctx, args, controller, transform, denom=global_batch, latent_cache=latent_cache, ids=idx)
+        if graphed is not None and not eager:
+            out = graphed(images)
+        else:
+            out = group_step(ldm, images, ctx, args, controller, transform, denom=global_batch, latent_cache=latent_cache, ids=idx)
         reducer.step()
         return out
 
@@ -733,11 +744,11 @@ def main():
             try:
                 ops.FLASH_SPLIT = False
                 for _ in range(2):
-                    one_step()
+                    one_step(eager=True)
                 torch.cuda.synchronize()
                 t0s = time.perf_counter()
                 for _ in range(a.steps):
-                    one_step()
+                    one_step(eager=True)
                 torch.cuda.synchronize()
                 el_s = time.perf_counter() - t0s
                 ops.FLASH_SPLIT = True
@@ -876,6 +887,10 @@ def main():
             "cpu_baseline": cpu_stats, "verify": verify, "collective_check": coll,
             "loss": float(last[0]), "setup_s": t_build, "cpu_baseline_s": t_cpu,
             "launch_thread_cpu_ms_per_step": c_launch / a.steps * 1e3,
+            "captured_step": ({"on": True, "what": "forward + losses + backward of a step replayed from one hipGraph (optimize.GraphedStep; inputs, "
+                                                   "noise and affines refreshed in static buffers before every replay); all-reduce + Adam eager",
+                               "group_sizes_captured": sorted(k for k, v in graphed.state.items() if v != "eager" and v.get("graph") is not None)}
+                              if graphed is not None else {"on": False}),
             "step_from_idle": {"launch_thread_returns_ms": t_issue * 1e3, "gpu_done_ms": t_idle_total * 1e3}, "prewarm_steps": 1, "gemm_tunableop_file": bool(gemm_tuned),
             "weights_init": weights_init,
         }

@@ -414,6 +414,11 @@ int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int 
                        const int32_t* argmax, int num_subjects, float sigma,
                        const float* theta_inv /*[host] 6*/, float* partial, float* g_sharp,
                        float* g_eq_a, float* g_eq_b, void* stream);
+/* ... with theta_inv [6] in DEVICE memory (read by the kernels, not at launch): the call can be captured in a hipGraph and replayed
+ * with a new augmentation per step (stablekeypoints_amd/optimize.py: GraphedStep). */
+int skp_losses_fwd_dev_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
+                           const int32_t* argmax, int num_subjects, float sigma, const float* theta_inv_dev,
+                           float* partial, float* g_sharp, float* g_eq_a, float* g_eq_b, void* stream);
 
 /* dst[sel[k], :] += a * x[k, :] + b * y[k, :]   (y may be NULL); rows of length n; sel i64[K] distinct. */
 int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t n, const float* x, const float* a,

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKP_LIB_PATH: another BUILD of the same library (same-box A/B of two kernel versions, tools/ab_build.py); never a fallback
 LIB_PATH = os.environ.get("SKP_LIB_PATH") or os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "skp_select_tokens": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "skp_select_tokens_batched": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "skp_losses_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, C.POINTER(_f), _vp, _vp, _vp, _vp, _vp],
+    "skp_losses_fwd_dev_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "skp_rows_axpy_f32": [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
     "skp_cross_attn_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "skp_cross_attn_bwd_workspace": [_i, _i, _i, _i, _i],

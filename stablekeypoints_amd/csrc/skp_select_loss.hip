@@ -244,7 +244,18 @@ struct LossArgs {
     int K, T, R, S, nchunk;
     float sigma;
     float th[6];                                                // inverse affine, row-major 2x3
+    const float* th_dev;                                        // ... or, if not null, read from device memory (captured steps)
 };
+// the argument block with the inverse affine in place (a captured hipGraph replays the same launch for a new affine every step:
+// the six numbers then come from a device buffer the host refreshes before the replay)
+__device__ __forceinline__ LossArgs skp_loss_args(const LossArgs& in) {
+    LossArgs a = in;
+    if (in.th_dev) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.th[i] = in.th_dev[i];
+    }
+    return a;
+}
 
 // Bilinear sample position of output pixel (col,row) in the transformed map: affine_grid + grid_sample with
 // align_corners=False (invertable_transform.py:72-92).  Explicitly rounded ops: the loss kernel and the gradient gather
@@ -270,10 +281,11 @@ __device__ __forceinline__ SkpBilin skp_bilin(const LossArgs& a, int col, int ro
 
 __global__ __launch_bounds__(256) void skp_losses_kernel(const float* __restrict__ M, const float* __restrict__ Mt,
                                                          const int64_t* __restrict__ sel,
-                                                         const int32_t* __restrict__ argmax, LossArgs a,
+                                                         const int32_t* __restrict__ argmax, LossArgs a_in,
                                                          float* __restrict__ partial, float* __restrict__ g_sharp,
                                                          float* __restrict__ g_eq_a) {
     __shared__ float red[4];
+    const LossArgs a = skp_loss_args(a_in);
     const int k = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int R = a.R, RR = R * R;
     const int tok = (int)sel[k];
@@ -328,8 +340,9 @@ __global__ __launch_bounds__(256) void skp_losses_kernel(const float* __restrict
 // collects -g_eq_a[p] * w(p -> s) from every output pixel p whose bilinear footprint contains it.  Those p lie in the
 // pre-image of the box (sx-1,sx+1) x (sy-1,sy+1) under the affine pixel map; its bounding box (+1 pixel of slack for
 // rounding) is scanned in row-major order and each candidate's footprint is recomputed with skp_bilin.
-__global__ __launch_bounds__(256) void skp_equiv_grad_kernel(LossArgs a, const float* __restrict__ g_eq_a,
+__global__ __launch_bounds__(256) void skp_equiv_grad_kernel(LossArgs a_in, const float* __restrict__ g_eq_a,
                                                             float* __restrict__ g_eq_b) {
+    const LossArgs a = skp_loss_args(a_in);
     const int k = blockIdx.y, R = a.R, RR = R * R;
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= RR) return;
@@ -367,16 +380,18 @@ __global__ __launch_bounds__(256) void skp_equiv_grad_kernel(LossArgs a, const f
     g_eq_b[(size_t)k * RR + s] = acc;
 }
 
-extern "C" int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
-                                  const int32_t* argmax, int num_subjects, float sigma, const float* theta_inv,
-                                  float* partial, float* g_sharp, float* g_eq_a, float* g_eq_b, void* stream) {
-    if (!M || !Mt || !sel || !argmax || !theta_inv || !partial || !g_sharp || !g_eq_a || !g_eq_b) return SKP_E_BADARG;
+static int losses_run(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R, const int32_t* argmax, int num_subjects,
+                      float sigma, const float* theta_inv_host, const float* theta_inv_dev, float* partial, float* g_sharp,
+                      float* g_eq_a, float* g_eq_b, void* stream) {
+    if (!M || !Mt || !sel || !argmax || (!theta_inv_host && !theta_inv_dev) || !partial || !g_sharp || !g_eq_a || !g_eq_b) return SKP_E_BADARG;
     if (K <= 0 || T <= 0 || R <= 0) return SKP_E_BADARG;
     if (num_subjects < 1 || num_subjects > SKP_MAX_SUBJECTS || K > 65535) return SKP_E_RANGE;
     LossArgs a{};
     a.K = K; a.T = T; a.R = R; a.S = num_subjects; a.sigma = sigma;
     a.nchunk = (R * R + 1023) / 1024;
-    for (int i = 0; i < 6; ++i) a.th[i] = theta_inv[i];
+    a.th_dev = theta_inv_dev;
+    if (theta_inv_host)
+        for (int i = 0; i < 6; ++i) a.th[i] = theta_inv_host[i];
     hipLaunchKernelGGL(skp_losses_kernel, dim3(a.nchunk, K), dim3(256), 0, (hipStream_t)stream, M, Mt, sel, argmax, a,
                        partial, g_sharp, g_eq_a);
     int rc = skp_launch_status();
@@ -384,6 +399,21 @@ extern "C" int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t
     hipLaunchKernelGGL(skp_equiv_grad_kernel, dim3((R * R + 255) / 256, K), dim3(256), 0, (hipStream_t)stream, a, g_eq_a,
                        g_eq_b);
     return skp_launch_status();
+}
+
+extern "C" int skp_losses_fwd_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
+                                  const int32_t* argmax, int num_subjects, float sigma, const float* theta_inv,
+                                  float* partial, float* g_sharp, float* g_eq_a, float* g_eq_b, void* stream) {
+    return losses_run(M, Mt, sel, K, T, R, argmax, num_subjects, sigma, theta_inv, nullptr, partial, g_sharp, g_eq_a, g_eq_b, stream);
+}
+
+// the same with the inverse affine (6 floats) in DEVICE memory, read by the kernels at run time: the launch can be captured in a
+// hipGraph and replayed for a new augmentation every step
+extern "C" int skp_losses_fwd_dev_f32(const float* M, const float* Mt, const int64_t* sel, int K, int T, int R,
+                                      const int32_t* argmax, int num_subjects, float sigma, const float* theta_inv_dev,
+                                      float* partial, float* g_sharp, float* g_eq_a, float* g_eq_b, void* stream) {
+    if (!theta_inv_dev) return SKP_E_BADARG;
+    return losses_run(M, Mt, sel, K, T, R, argmax, num_subjects, sigma, nullptr, theta_inv_dev, partial, g_sharp, g_eq_a, g_eq_b, stream);
 }
 
 // dst[sel[k], :] += a*x[k,:] + b*y[k,:]
@@ -408,7 +438,7 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 36; }
+extern "C" int skp_abi_version(void) { return 37; }
 
 // ---- developer overrides (include/skp.h: skp_tune_set) ----
 static int g_tune[SKP_TUNE_COUNT] = {0};

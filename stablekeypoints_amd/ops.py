@@ -423,7 +423,8 @@ class MapLossesFn(torch.autograd.Function):
         backward: G = go_sharp * g_sharp + go_equiv * g_eq (K rows per batch row) -> sparse token-major map backward
                   (csrc/skp_attn_map_tok.hip) -> dq_l, dk_l on the fp32-MFMA GEMM.
     apply(meta, q_0, k_0, q_1, k_1, ...) with rows 0..n-1 = the images, n..2n-1 = their affine copies;
-    meta = dict(R, heads, scales, thetas [n][6], sigma, num_subjects, strategy, n_cand, top_k, score_fn).
+    meta = dict(R, heads, scales, thetas [n][6] (host) or theta_inv_dev [n,6] (device), sigma, num_subjects, strategy, n_cand,
+    top_k, score_fn).
     Returns (sum_i sharp_i, sum_i equiv_i, sel [n,K] int64)."""
 
     @staticmethod
@@ -434,7 +435,10 @@ class MapLossesFn(torch.autograd.Function):
         R, H, scales = int(meta["R"]), int(meta["heads"]), tuple(float(v) for v in meta["scales"])
         B, T = qs[0].shape[0], ks[0].shape[1]
         n = B // 2
-        if B != 2 * n or len(scales) != L or len(meta["thetas"]) != n:
+        th_dev = meta.get("theta_inv_dev")          # [n, 6] float32 on the device, instead of meta["thetas"] (host numbers)
+        if th_dev is not None and (not th_dev.is_cuda or th_dev.dtype != torch.float32 or tuple(th_dev.shape) != (n, 6) or not th_dev.is_contiguous()):
+            raise RuntimeError("MapLossesFn: theta_inv_dev must be a contiguous float32 [n, 6] device tensor")
+        if B != 2 * n or len(scales) != L or (th_dev is None and len(meta["thetas"]) != n):
             raise RuntimeError("MapLossesFn: rows must be n images followed by their n affine copies, one scale per layer")
         sides = []
         for q, k in zip(qs, ks):
@@ -484,6 +488,12 @@ class MapLossesFn(torch.autograd.Function):
                 am_t, _ = token_stats(M[n + i], num_subjects=1, sigma=sigma, want_kl=False)
                 _, sel_i = select_tokens(score, am_t[0], R, n_cand, K)
                 sel_all[i].copy_(sel_i)
+            if th_dev is not None:                   # inverse affines in device memory (a captured step: new numbers per replay)
+                N.check(lib.skp_losses_fwd_dev_f32(M[i].data_ptr(), M[n + i].data_ptr(), sel_all[i].data_ptr(), K, T, R,
+                                                   am.data_ptr(), ns, sigma, th_dev[i].data_ptr(), partial[i].data_ptr(),
+                                                   g_sharp[i].data_ptr(), g_eq_a[i].data_ptr(), g_eq_b[i].data_ptr(), st),
+                        "skp_losses_fwd_dev_f32")
+                continue
             th, _keep = N.float_array(invert_affine(meta["thetas"][i]))
             N.check(lib.skp_losses_fwd_f32(M[i].data_ptr(), M[n + i].data_ptr(), sel_all[i].data_ptr(), K, T, R,
                                            am.data_ptr(), ns, sigma, th, partial[i].data_ptr(), g_sharp[i].data_ptr(),

@@ -206,7 +206,7 @@ def token_order(attn_map, strategy, num_subjects, sigma):
 token_order._skp_stock_order = True         # ops.MapLossesFn batches the statistics of all images only for this scoring
 
 
-def _group_losses(controller, thetas, args, n):
+def _group_losses(controller, thetas, args, n, theta_inv_dev=None):
     """(sum_i equiv_i, sum_i sharp_i) of the 2n stored rows.  Default: ONE autograd node from the hooked layers' q / k to
     the two loss sums (ops.MapLossesFn), whose backward hands the map kernels the gradient as K selected rows per batch
     row -- taken where it is the faster one (T > 128 by default, see ops.MAP_BWD_MODE).  Otherwise the general route:
@@ -216,9 +216,14 @@ def _group_losses(controller, thetas, args, n):
     T = records[0].k.shape[1]
     n_cand = min(args.furthest_point_num_samples, T)
     K = min(args.top_k, n_cand)
-    if ops.map_bwd_sparse_supported(sides, K, records[0].R, T, records[0].heads) and K >= 2:
+    fused = ops.map_bwd_sparse_supported(sides, K, records[0].R, T, records[0].heads) and K >= 2
+    controller.fused_route = bool(fused)                          # GraphedStep captures only steps that take the fused node
+    if theta_inv_dev is not None and not fused:
+        raise RuntimeError("_group_losses: device-resident affines are served by the fused map + losses node only")
+    if fused:
         meta = dict(R=records[0].R, heads=records[0].heads, scales=[r.scale for r in records],
-                    thetas=[thetas[i].reshape(-1).tolist() for i in range(n)], sigma=args.sigma,
+                    thetas=None if theta_inv_dev is not None else [thetas[i].reshape(-1).tolist() for i in range(n)],
+                    theta_inv_dev=theta_inv_dev, sigma=args.sigma,
                     num_subjects=getattr(args, "num_subjects", 1), strategy=getattr(args, "top_k_strategy", "gaussian"),
                     n_cand=n_cand, top_k=K, score_fn=token_order)
         flat = []
@@ -276,6 +281,110 @@ def group_step(ldm, images, context, args, controller, transform, denom, noise=N
     return loss.detach(), tot_e.detach() / denom, tot_s.detach() / denom
 
 
+class GraphedStep:
+    """`group_step` as a captured hipGraph (torch.cuda.graphs): forward of both views, losses and the backward into
+    `context.grad`, replayed once per group; the all-reduce and Adam stay outside (`EmbeddingReducer.step`).
+
+    Why: a step is ~670-800 launches whatever its batch.  At 4 images per group the launch thread is done in a quarter of the
+    step's 76 ms; at 1 image (BASELINE config 3's per-rank shape, B = 2 rows) the same launches have to go out in ~26 ms: the
+    thread needs 18-26 ms of host time for them depending on the host (profiles/r06_summary.md: 26.6 ms per step on one box,
+    28.2 on a slower one, with eight ranks sharing a host still to come).  Replaying the graph costs 3.4 ms of host time; the
+    GPU time is unchanged (26.7 vs 26.4 ms on the fast-host box).
+
+    What it takes: nothing inside the step may come from the host.  The images, the noise of both views, the forward affines
+    (for the warp) and their inverses (for the equivariance term: `skp_losses_fwd_dev_f32` reads them from device memory) live
+    in static buffers refreshed before every replay -- the thetas are still drawn on the host in the reference's order
+    (invertable_transform.py:22-57), the noise by the same device generator call as the eager step, so a seeded run sees the
+    same draws in both modes.  Token selection never left the device anyway.  The first `warmup` calls of a group size run
+    eagerly (real steps: caches of the frozen weights fill, the route is known); a group size whose step does not take the
+    fused map + losses node, or whose capture fails, stays eager (one warning).  One graph (and one private memory pool) per
+    group size."""
+
+    def __init__(self, ldm, context, args, controller, transform, denom, warmup=2, warn_route=True):
+        self.ldm, self.context, self.args, self.controller, self.transform = ldm, context, args, controller, transform
+        self.denom, self.warmup, self.warn_route = denom, int(warmup), bool(warn_route)
+        self.dev = context.device
+        self.state = {}                                           # group size -> dict(calls, graph, buffers) or "eager"
+
+    def _body(self, st):
+        n, dev, args = st["n"], self.dev, self.args
+        images = st["images"]
+        warped = F.grid_sample(images, F.affine_grid(st["theta"], images.size(), align_corners=False), align_corners=False)
+        ptp_utils.find_pred_noise(self.ldm, torch.cat([images, warped], dim=0), self.context, noise_level=args.noise_level,
+                                  device=dev, noise=st["noise"], early_exit=True, controllers={dev: self.controller})
+        tot_e, tot_s = _group_losses(self.controller, None, args, n, theta_inv_dev=st["theta_inv"])
+        loss = (tot_e * args.equivariance_attn_loss_weight + tot_s * args.sharpening_loss_weight) / self.denom
+        loss.backward()
+        st["out"].copy_(torch.stack([loss.detach(), tot_e.detach() / self.denom, tot_s.detach() / self.denom]))
+
+    def _capture(self, st, images):
+        n, dev = st["n"], self.dev
+        with torch.no_grad():
+            lat = ptp_utils.image2latent(self.ldm, images[:1].to(dev), dev)       # latent geometry of this image size
+        st["images"] = torch.empty(n, *images.shape[1:], device=dev, dtype=torch.float32)
+        st["theta"] = torch.empty(n, 2, 3, device=dev)
+        st["theta_inv"] = torch.empty(n, 6, device=dev)
+        st["noise"] = torch.empty(2 * n, *lat.shape[1:], device=dev)
+        st["out"] = torch.zeros(3, device=dev)
+        # valid contents while the graph is recorded (zeros for the noise: recording must not consume the generator)
+        self._stage(st, images, torch.eye(2, 3).repeat(n, 1, 1), torch.zeros_like(st["noise"]))
+        if self.context.grad is None:
+            self.context.grad = torch.zeros_like(self.context)    # the captured backward ACCUMULATES into this tensor
+        st["grad"] = self.context.grad
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._body(st)
+        st["graph"] = graph
+
+    def _stage(self, st, images, thetas, noise):
+        n = st["n"]
+        host = torch.empty(n, 12, pin_memory=True)                # recycled by the host allocator only after the copy has run
+        th = thetas.detach().to("cpu", torch.float32).reshape(n, 6)
+        host[:, :6] = th
+        host[:, 6:] = torch.tensor([ops.invert_affine(th[i].tolist()) for i in range(n)], dtype=torch.float32)
+        st["theta"].copy_(host[:, :6].reshape(n, 2, 3), non_blocking=True)
+        st["theta_inv"].copy_(host[:, 6:], non_blocking=True)
+        st["images"].copy_(images, non_blocking=True)
+        if noise is None:
+            st["noise"].normal_()                                 # the draw `find_pred_noise` makes in the eager step (same generator, same shape)
+        else:
+            st["noise"].copy_(noise, non_blocking=True)
+
+    def __call__(self, images, noise=None, thetas=None):
+        """-> detached (total, equiv, sharp) like `group_step` (views of a static buffer: read them before the next call)."""
+        n = int(images.shape[0])
+        st = self.state.setdefault(n, {"n": n, "calls": 0})
+        if st != "eager" and st.get("graph") is None and st["calls"] >= self.warmup:
+            import warnings
+            if not getattr(self.controller, "fused_route", False):
+                if self.warn_route:
+                    warnings.warn(f"GraphedStep: groups of {n} images stay on eager launches (the step does not take the fused map + "
+                                  "losses node at these shapes)")
+                self.state[n] = st = "eager"
+            else:
+                try:
+                    self._capture(st, images)
+                except Exception as e:                           # noqa: BLE001 -- capture is an optimisation of the host side only
+                    warnings.warn(f"GraphedStep: groups of {n} images stay on eager launches (capture failed: {e})")
+                    self.controller.reset()
+                    self.state[n] = st = "eager"
+        if st == "eager" or st.get("graph") is None:
+            if st != "eager":
+                st["calls"] += 1
+            return group_step(self.ldm, images, self.context, self.args, self.controller, self.transform, self.denom,
+                              noise=noise, thetas=thetas)
+        if self.context.grad is not st["grad"]:                   # somebody dropped / replaced the gradient: the graph adds into ITS tensor
+            st["grad"].zero_()
+            self.context.grad = st["grad"]
+        if thetas is None:
+            thetas = self.transform.sample_theta(n)               # the host draws of the eager step, same order
+        self.transform.last_theta_host = thetas
+        self._stage(st, images, thetas, noise)
+        st["graph"].replay()
+        out = st["out"]
+        return out[0], out[1], out[2]
+
+
 def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
                        from_where=["down_cross", "mid_cross", "up_cross"], draws=None, trajectory_out=None,
                        step_callback=None):
@@ -313,6 +422,12 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
     cache_max = int(getattr(args, "cache_latents_max", 200_000))
     loader = GroupLoader(dataset, _group_indices(args, len(dataset), draws, accum, group, rank, world), dev,
                          workers=int(getattr(args, "loader_workers", 4)))
+    # small groups are launch-bound on the host: their step is captured once and replayed (GraphedStep); "auto" = groups of <= 2
+    # images on a GPU, without the latent cache (which decides per image what to encode)
+    cap = getattr(args, "capture_step", "auto")
+    graphed = None
+    if dev.type == "cuda" and latent_cache is None and (cap == "on" or (cap == "auto" and group <= 2)):
+        graphed = GraphedStep(ldm, context, args, controller, transform, args.batch_size, warn_route=(cap == "on"))
     start = it_start = time.time()
     try:
         for step in range(int(args.num_steps)):
@@ -327,8 +442,11 @@ def optimize_embedding(ldm, args, controllers, num_gpus, context=None,
                     inject = dict(noise=torch.cat([pair[0::2], pair[1::2]]), thetas=torch.as_tensor(draws[2][it:it + n]))
                 if latent_cache is not None and len(latent_cache) + n > cache_max:
                     latent_cache.clear()
-                running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size,
-                                                  latent_cache=latent_cache, ids=idx, **inject))
+                if graphed is not None:
+                    running += torch.stack(graphed(images, **inject))
+                else:
+                    running += torch.stack(group_step(ldm, images, context, args, controller, transform, args.batch_size,
+                                                      latent_cache=latent_cache, ids=idx, **inject))
                 done += n
             reducer.step()
             if trajectory_out is not None:
@@ -358,6 +476,6 @@ def default_args(**over):
              equivariance_attn_loss_weight=1000, layers=[0, 1, 2, 3], noise_level=-1, sigma=2.0,
              augment_degrees=15, augment_scale=[0.8, 1.0], augment_translate=[0.25, 0.25], wandb=False,
              model_type="sd-legacy/stable-diffusion-v1-5", seed=0, image_size=512, log_interval=50,
-             cache_latents=False, cache_latents_max=200_000, loader_workers=4)
+             cache_latents=False, cache_latents_max=200_000, loader_workers=4, capture_step="auto")
     a.update(over)
     return SimpleNamespace(**a)

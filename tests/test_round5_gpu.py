@@ -109,6 +109,8 @@ def test_optimize_embedding_host_folder_prefetch_is_order_identical(tmp_path):
     (3, 1, 2, 64, 500, 40),           # one k / v shared by all rows (cross-attention with many tokens)
     (2, 2, 8, 1024, 1024, 80),        # d % 16 == 0: VALU row sums, the full 160 KB of LDS
     (1, 1, 3, 100, 77, 80),           # a single ragged tile
+    (4, 4, 8, 2048, 2048, 40),        # >= 256 workgroups of 256 queries: 32 queries per wave (the shapes above run 16 per wave)
+    (4, 4, 8, 2048, 2048, 80),
 ])
 def test_split_bf16_flash_attention_forward_vs_fp64(B, Bk, H, N, Nk, d):
     """skp_flash_attn_fwd_split_f32 against fp64 softmax(scale q k^T) v and against the fp32-instruction kernel on the same

@@ -115,3 +115,56 @@ def test_sd15_step_at_load_ldm_default_res_256_vs_oracle(sd15_cpu):
     assert abs(sh.item() - sharp_ref) < 1e-3 * abs(sharp_ref)
     assert abs(eq.item() - equiv_ref) < 2e-3 * abs(equiv_ref)
     assert_grad_close(c_gpu.grad, gref, "sd15 512^2, R = 256 (load_ldm default)")
+
+
+def test_graphed_step_replays_the_eager_step():
+    """`optimize.GraphedStep`: forward + losses + backward of a group captured in a hipGraph and replayed with new images, noise and
+    affines per call (static buffers; the inverse affines read from device memory by skp_losses_fwd_dev_f32).  Reduced-width tree at
+    512^2 / R = 128 (the shapes whose step takes the fused node), 1 image per group: five steps, each against the eager
+    `group_step` on the same inputs -- losses and the accumulated embedding gradient (same kernels; the libraries may pick their
+    algorithms per stream, hence 1e-5 of the maximum instead of bit equality) -- then with the noise and the thetas drawn by the
+    step itself under one seed: the same draws in both modes."""
+    from test_e2e_gpu import _setup
+    from stablekeypoints_amd.invertable_transform import RandomAffineWithInverse
+    from stablekeypoints_amd.optimize import GraphedStep, group_step
+    ldm, controllers, cpu, images, ctx, noise, args = _setup(R_up=128, T=16, n=2, size=512)
+    del cpu
+    dev, controller = next(iter(controllers.items()))
+    g = torch.Generator().manual_seed(5)
+    tr_a, tr_b = RandomAffineWithInverse(15, (0.8, 1.0), (0.25, 0.25)), RandomAffineWithInverse(15, (0.8, 1.0), (0.25, 0.25))
+    c_e = ctx.clone().cuda().requires_grad_(True)
+    c_g = ctx.clone().cuda().requires_grad_(True)
+    graphed = GraphedStep(ldm, c_g, args, controller, tr_b, denom=1, warmup=2)
+    for step in range(5):
+        img = torch.rand(1, 3, 512, 512, generator=g)
+        nz = torch.randn(2, 4, 64, 64, generator=g).cuda()
+        th = R.affine_matrix(float(torch.rand(1, generator=g)) * 20 - 10, 0.85 + 0.1 * float(torch.rand(1, generator=g)), (0.1, -0.05 * step))
+        le = group_step(ldm, img, c_e, args, controller, tr_a, denom=1, noise=nz, thetas=th)
+        lg = [v.clone() for v in graphed(img, noise=nz, thetas=th)]
+        for a_, b_ in zip(le, lg):
+            assert abs(a_.item() - b_.item()) <= 1e-5 * abs(a_.item()) + 1e-9, (step, a_.item(), b_.item())
+        assert_grad_close(c_g.grad, c_e.grad, f"graphed vs eager, step {step}", tol=1e-5)     # gradients ACCUMULATE over the five steps
+    st = graphed.state[1]
+    assert st != "eager" and st["graph"] is not None and st["calls"] == 2, "steps 3-5 must have been replays"
+    # draws made by the step itself: same generators, same order
+    c_e.grad = None
+    c_g.grad.zero_()
+    img = torch.rand(1, 3, 512, 512, generator=g)
+    torch.manual_seed(77)
+    le = group_step(ldm, img, c_e, args, controller, tr_a, denom=1)
+    torch.manual_seed(77)
+    lg = [v.clone() for v in graphed(img)]
+    assert torch.equal(tr_a.last_theta_host, tr_b.last_theta_host)
+    assert abs(le[0].item() - lg[0].item()) <= 1e-5 * abs(le[0].item())
+    assert_grad_close(c_g.grad, c_e.grad, "graphed vs eager, own draws", tol=1e-5)
+    # a group size whose step does not take the fused node stays eager, with one warning
+    ldm2, controllers2, _, images2, ctx2, noise2, args2 = _setup()            # R = 32: image-by-image losses
+    dev2, controller2 = next(iter(controllers2.items()))
+    c2 = ctx2.clone().cuda().requires_grad_(True)
+    g2 = GraphedStep(ldm2, c2, args2, controller2, RandomAffineWithInverse(), denom=2, warmup=1)
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            g2(images2)
+    assert g2.state[2] == "eager" and sum("stay on eager" in str(x.message) for x in w) == 1
