@@ -297,6 +297,16 @@ def test_sd15_config2_shape_step_vs_oracle(n_img, sd15_cpu):
     assert abs(eq_g.item() - ref_equiv) < 2e-3 * abs(ref_equiv)
     print("config-2 shape grad: |g|max", gref.abs().max().item(), "max abs diff", (c_gpu.grad.cpu() - gref).abs().max().item())
     assert_grad_close(c_gpu.grad, gref, "test_round4_gpu.py#1")
+    if n_img == 1:
+        # config 3's per-rank step is launch-bound on the host and runs as a captured hipGraph (optimize.GraphedStep, the product's
+        # rule for groups of <= 2 images): the replayed step against the same oracle gradient
+        from stablekeypoints_amd.optimize import GraphedStep
+        c_rep = ctx.clone().cuda().requires_grad_(True)
+        graphed = GraphedStep(ldm, c_rep, args, controller, tr, denom=n_img, warmup=0)
+        lg = graphed(images, noise=noise.cuda(), thetas=thetas)
+        assert graphed.state[1] != "eager" and graphed.state[1]["graph"] is not None
+        assert abs(lg[2].item() - ref_sharp) < 1e-3 * abs(ref_sharp) and abs(lg[1].item() - ref_equiv) < 2e-3 * abs(ref_equiv)
+        assert_grad_close(c_rep.grad, gref, "config 3 per-rank step, replayed from the hipGraph")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -14,10 +14,10 @@ for ipr in 4 1; do
   rm -rf $O/kt$sfx
 done
 cd $R
-for cfg in "--images-per-rank 1" "--images-per-rank 2" "--tokens 500" "--scaling strong --global-batch 8" "--model sd21 --top-k 30 --candidates 50" "--model sdxl --images-per-rank 2"; do
+for cfg in "--images-per-rank 1" "--images-per-rank 2" "--images-per-rank 1 --graph off" "--images-per-rank 2 --graph off" "--tokens 500" "--scaling strong --global-batch 8" "--model sd21 --top-k 30 --candidates 50" "--model sdxl --images-per-rank 2"; do
   n=$(echo $cfg | tr -d " -"); python bench.py $cfg --steps 10 --warmup 3 --cpu-baseline off --verify off --traffic off > $O/cfg_$n.log 2>&1; grep '^{' $O/cfg_$n.log > $O/cfg_$n.json
   python -c "
-import json; d=json.load(open('$O/cfg_$n.json')); print('$n', round(d['value'],3), round(d['ms_per_step'],2), (d.get('f32_instr') or {}).get('ms_per_step'), d.get('step_from_idle'))"; done
+import json; d=json.load(open('$O/cfg_$n.json')); print('$n', round(d['value'],3), round(d['ms_per_step'],2), (d.get('f32_instr') or {}).get('ms_per_step'), round(d['launch_thread_cpu_ms_per_step'],2), d.get('step_from_idle'), d['captured_step'].get('group_sizes_captured'))"; done
 bash tools/prof_kernels.sh map6 tools/map_bench.py --skip-dense --iters 3 > $O/pmc_map.log 2>&1; cp gpurun_out/prof_map6/pmc_summary.json $O/pmc_map.json 2>/dev/null
 python tools/rccl_smoke.py > $O/rccl_smoke.json 2>$O/rccl_smoke.err
 python -c "
