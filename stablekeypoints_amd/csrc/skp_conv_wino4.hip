@@ -930,14 +930,17 @@ int wino4_plan(int B, int Cin, int Cout, int H, int W) {
     double best_cost = 1e30;
     // measured stage times (us): the 128-channel form ~3.9, the 64-channel form ~5.6 (tools/conv_bench.py with SKP_WINO_SPLIT
     // forced); the reduce pass streams (S + 1) x the output at ~8 TB/s (the partials are L2 / MALL resident)
-    const double stage_us = c128 ? 3.9 : 5.6;
+    // (ragged channel counts -- 320 = 2.5 groups of 128 -- pay a full stage for the half-idle group: 4.8 us per stage and a K split
+    // already at 5 % gain, tools/split_sweep.py, round 6: 320 -> 320 @64^2 at 8 rows S = 1 215 us, S = 2 195 us)
+    const bool ragged_c128 = c128 && (Cout % 128) != 0;
+    const double stage_us = c128 ? (ragged_c128 ? 4.8 : 3.9) : 5.6;
     for (int S = 1; S <= 16; ++S) {
         const int per = (nsteps + S - 1) / S;
         if ((S - 1) * per >= nsteps) continue;                   // an empty last split
         const Wino4Grid g = wino4_grid(Cout, tiles, S);
         double cost = g.rounds * (per + 2.0) * stage_us;       // ~2 stages of prologue + epilogue per workgroup
         if (S > 1) cost += 6.0 + (S + 1) * out_bytes / 8.0e6;
-        if (cost < best_cost * (S > 1 ? 0.92 : 1.0)) { best_cost = cost; best = S; }
+        if (cost < best_cost * (S > 1 ? (ragged_c128 ? 0.95 : 0.92) : 1.0)) { best_cost = cost; best = S; }
     }
     return best;
 }
