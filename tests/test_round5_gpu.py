@@ -140,7 +140,7 @@ def test_split_bf16_flash_attention_forward_vs_fp64(B, Bk, H, N, Nk, d):
     e_s, e_32 = (out.cpu().double() - ref).abs().max().item() / sref, (o32.cpu().double() - ref).abs().max().item() / sref
     el_s, el_32 = (lse.cpu().double() - ref_lse).abs().max().item(), (l32.cpu().double() - ref_lse).abs().max().item()
     print(f"d={d} N={N} Nk={Nk}: out err split {e_s:.2e} fp32 {e_32:.2e} (ratio {e_s / e_32:.2f}); lse err split {el_s:.2e} fp32 {el_32:.2e}")
-    assert e_s <= 1.5 * e_32 + 1e-7 and e_s < 2e-6
+    assert e_s <= 1.5 * e_32 + 1e-7 and e_s < (2e-6 if Nk <= 1024 else 1e-5)      # (the spiked key's error grows with the key count: 5e-6 at 2048, fp32 kernel 1.4e-5)
     assert el_s <= 1.5 * el_32 + 2e-6
     out2, lse2 = ops.flash_attn_fwd_split(qg, kg, vg, H, scale)
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
