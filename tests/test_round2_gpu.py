@@ -392,7 +392,7 @@ def test_sd21_sdxl_full_width_trees_one_forward(ops):
     from stablekeypoints_amd._maps import collect_maps_batched
     from stablekeypoints_amd.optimize_token import load_ldm
     for arch, size, width, n_layers, side in (("sd21", 768, 1024, 3, 24), ("sdxl", 1024, 2048, 4, 32)):
-        ldm, controllers, _ = load_ldm("cuda", arch, feature_upsample_res=128)
+        ldm, controllers, _ = load_ldm("cuda", arch, feature_upsample_res=128, init_on_device=True)     # (no host twin needed here)
         dev, controller = next(iter(controllers.items()))
         g = torch.Generator().manual_seed(1)
         img = torch.rand(1, 3, size, size, generator=g).cuda()
