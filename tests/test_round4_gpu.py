@@ -228,6 +228,9 @@ def test_g11_two_ranks_vs_reference(tmp_path, golden):
 # ---------------------------------------------------------------------------------------------------------------------
 # a whole step at config 2's launch shape
 # ---------------------------------------------------------------------------------------------------------------------
+_ORACLE_IMAGE_STEPS = {}          # image index -> the oracle's step for that image (test_sd15_config2_shape_step_vs_oracle)
+
+
 @pytest.mark.parametrize("n_img", [4, 1])
 def test_sd15_config2_shape_step_vs_oracle(n_img, sd15_cpu):
     """n_img = 1 is BASELINE config 3's PER-RANK shape (8 images over 8 ranks: 1 image x 2 views, B = 2 rows -- the K-split
@@ -248,28 +251,35 @@ def test_sd15_config2_shape_step_vs_oracle(n_img, sd15_cpu):
     Rup, T, n_cand, top_k = 128, 77, 25, 10
     ldm, controllers, _ = load_ldm("cuda", "sd15", feature_upsample_res=Rup)
     cpu = sd15_cpu
+    # one set of inputs for both cases (four images; the 1-image case is image 0 with its two noise rows): the oracle's per-image
+    # step depends on (image, embedding, theta, the two noise rows) only, so its result for an image is computed once per session
     g = torch.Generator().manual_seed(7)
-    images = torch.rand(n_img, 3, 512, 512, generator=g)
+    images4 = torch.rand(4, 3, 512, 512, generator=g)
     ctx = torch.randn(1, T, 768, generator=g) * 5.0
-    noise = torch.randn(2 * n_img, 4, 64, 64, generator=g)          # rows 0..n-1: the images, n..2n-1: their affine copies
-    thetas = torch.cat([R.affine_matrix(a, s, tr) for a, s, tr in
-                        ((9.0, 0.9, (0.1, -0.15)), (-12.0, 0.85, (-0.2, 0.05)), (4.0, 0.97, (0.0, 0.22)), (-7.0, 0.8, (0.18, 0.1)))[:n_img]])
+    noise4 = torch.randn(8, 4, 64, 64, generator=g)                 # rows 0..3: the images, 4..7: their affine copies
+    thetas4 = torch.cat([R.affine_matrix(a, s, tr) for a, s, tr in
+                         ((9.0, 0.9, (0.1, -0.15)), (-12.0, 0.85, (-0.2, 0.05)), (4.0, 0.97, (0.0, 0.22)), (-7.0, 0.8, (0.18, 0.1)))])
+    images, thetas = images4[:n_img], thetas4[:n_img]
+    noise = torch.cat([noise4[:n_img], noise4[4:4 + n_img]])
     args = default_args(num_tokens=T, feature_upsample_res=Rup, furthest_point_num_samples=n_cand, top_k=top_k, batch_size=n_img)
     store = R.OracleStore()
     assert cpu_path.register_reference_hook(cpu.unet, store, Rup) == 18
     ref_maps, ref_sel, ref_sharp, ref_equiv = [], [], 0.0, 0.0
     gref = torch.zeros(1, T, 768)
     for i in range(n_img):
-        c_ref = ctx.clone().requires_grad_(True)
-        loss, sharp, equiv, sel, am, am_t = cpu_path.image_step(
-            cpu, images[i:i + 1], c_ref, store, thetas[i:i + 1], noise[i:i + 1], noise[n_img + i:n_img + i + 1],
-            furthest_point_num_samples=n_cand, top_k=top_k, sigma=args.sigma)
-        loss.backward()
-        gref += c_ref.grad / n_img                                   # optimize.py:418-420: loss / accumulation steps
-        ref_maps.append((am.detach(), am_t.detach()))
+        if i not in _ORACLE_IMAGE_STEPS:
+            c_ref = ctx.clone().requires_grad_(True)
+            loss, sharp, equiv, sel, am, am_t = cpu_path.image_step(
+                cpu, images[i:i + 1], c_ref, store, thetas[i:i + 1], noise[i:i + 1], noise[n_img + i:n_img + i + 1],
+                furthest_point_num_samples=n_cand, top_k=top_k, sigma=args.sigma)
+            loss.backward()
+            _ORACLE_IMAGE_STEPS[i] = (c_ref.grad.clone(), am.detach(), am_t.detach(), sel, sharp.item(), equiv.item())
+        g_i, am, am_t, sel, sharp_i, equiv_i = _ORACLE_IMAGE_STEPS[i]
+        gref += g_i / n_img                                          # optimize.py:418-420: loss / accumulation steps
+        ref_maps.append((am, am_t))
         ref_sel.append(sel)
-        ref_sharp += sharp.item() / n_img
-        ref_equiv += equiv.item() / n_img
+        ref_sharp += sharp_i / n_img
+        ref_equiv += equiv_i / n_img
     dev, controller = next(iter(controllers.items()))
     tr = RandomAffineWithInverse()
     with torch.no_grad():
