@@ -638,9 +638,9 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     const int tl = tid & 15, tc = tid >> 4;          // tile in the block, channel in the stage
     int roff[6];
     bool lok, rok;
+    int edelta = 0;                                  // byte offset of the halo value an END lane of the block loads (0: none)
     int coff = SKP_OOB;                              // GNF: per-(image, channel) coefficients of the stage's channel `tc`
     f32x2 mrow = {1.f, 1.f};                         // GNF: shift masks of patch rows 0 / 5 (0 outside the image) ...
-    f32x2 mcol = {1.f, 1.f};                         // ... and of patch columns 0 / 5 (the pair d[i][0]); fixed per unit
     f32x2 gh_edge = {0.f, 0.f};                      // per stage: shift of the (c0, c5) pair in rows 1..4
     unsigned rowmask = 0;
     auto aim_transform = [&](int tb, bool valid) {   // point the transform role at tile block tb (nothing: every load returns 0)
@@ -659,10 +659,13 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
         }
         lok = tx > 0;
         rok = tx + 1 < a.tilesX;
+        // halo columns: the neighbour tiles of a patch row sit in the neighbour lanes (16 consecutive tiles of a tile row per wave
+        // row), so columns 0 / 5 come from their aligned loads by DPP; only the block's two END lanes load a halo value (one
+        // masked load per patch row instead of two full ones)
+        edelta = tl == 0 ? (lok ? -4 : 0) : (tl == 15 ? (rok ? 16 : 0) : 0);
         coff = valid ? (b * a.Cin + tc) * 8 : SKP_OOB;
         if (GNF) {
             mrow = f32x2{(rowmask & 1u) ? 1.f : 0.f, (rowmask & 32u) ? 1.f : 0.f};
-            mcol = f32x2{lok ? 1.f : 0.f, rok ? 1.f : 0.f};
         }
     };
     aim_transform(tblock, true);
@@ -673,39 +676,55 @@ __global__ __launch_bounds__(256, 1) void skp_wino4_conv_c128_kernel(Wino4Args a
     f32x2 gcoef = {0.f, 0.f};
     f32x2 d[6][3];                                   // [row][column pair]: (c0,c5), (c1,c2), (c3,c4)
     auto gn_fetch = [&](int cin0) { if (GNF) gcoef = skp_buf_load_f32x2(crs, coff, cin0 * 8, 0); };
-    auto gn_prep = [&]() { if (GNF) gh_edge = f32x2{gcoef[1] * mcol[0], gcoef[1] * mcol[1]}; };
+    auto gn_prep = [&]() { if (GNF) gh_edge = f32x2{edelta != 0 ? gcoef[1] : 0.f, 0.f}; };
     // GNF: v = x * s + h;  silu(v) = v * rcp(1 + 2^(-v log2 e)) on value PAIRS (the patch registers are column pairs): two
     // packed fmas / muls, a packed add and a packed multiply per pair plus the four quarter-rate transcendentals -- an IEEE
     // division here is ten VALU instructions per value, all of them added to the MFMA time.  Zero padding must stay zero
     // although silu(0 * s + h) is not: a loaded 0 of an out-of-image row / column gets shift 0 as well.  Only patch rows 0 and 5
     // and patch columns 0 and 5 can lie outside the image, so the shift is masked per (row class, column class) with float
     // masks that are fixed per unit (aim_transform), four multiplies per stage instead of selects per row.
+    // columns 0 / 5 of patch row i from the neighbour lanes' columns 4 / 1 (row_shr:1 / row_shl:1 inside the 16-lane tile group); the
+    // end lanes keep what they loaded (d[i][0][0]); a tile at the image's left / right border gets 0 (zero padding)
+    auto halo_row = [&](int i, float edge) {
+        const float c4 = d[i][2][1], c1 = d[i][1][0];       // (by value: __builtin_bit_cast of a vector-element lvalue reads element 0)
+        const float fromL = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c4), 0x111, 0xf, 0xf, true));
+        const float fromR = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c1), 0x101, 0xf, 0xf, true));
+        d[i][0][0] = tl == 0 ? edge : (lok ? fromL : 0.f);
+        d[i][0][1] = tl == 15 ? edge : (rok ? fromR : 0.f);
+    };
     auto gn_row = [&](int i) {                       // normalise + SiLU row i of the freshly loaded patch
         if (GNF) {
             const float rm = i == 0 ? mrow[0] : (i == 5 ? mrow[1] : 1.0f);
             const f32x2 S2 = {gcoef[0], gcoef[0]};
             const f32x2 Hm = {gcoef[1] * rm, gcoef[1] * rm};                 // rows 1..4: rm == 1 folds away
-            const f32x2 He = (i == 0 || i == 5) ? f32x2{gh_edge[0] * rm, gh_edge[1] * rm} : gh_edge;
             auto act2 = [&](f32x2 x, f32x2 h) {
                 const f32x2 v = x * S2 + h;
                 const f32x2 z = v * (-SKP_LOG2E);
                 const f32x2 w = f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + 1.0f;
                 return v * f32x2{__builtin_amdgcn_rcpf(w[0]), __builtin_amdgcn_rcpf(w[1])};
             };
-            d[i][0] = act2(d[i][0], He);
             d[i][1] = act2(d[i][1], Hm);
             d[i][2] = act2(d[i][2], Hm);
+            // the end lanes' own halo value: one activation (the other lanes take their neighbours' activated columns); a value
+            // outside the image is a loaded 0 and must stay 0: its shift is masked (gh_edge: shift x (lane has an in-image halo))
+            const float he = (i == 0 || i == 5) ? gh_edge[0] * rm : gh_edge[0];
+            const float v = d[i][0][0] * gcoef[0] + he;
+            const float e = v * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * (-SKP_LOG2E)) + 1.0f);
+            halo_row(i, e);
         }
     };
     auto load_row = [&](int cin0, int i) {
         const int so = cin0 * HW * 4;
         const f32x4 mid = skp_buf_load_f32x4(xrs, roff[i], so, 0);
-        d[i][0][0] = skp_buf_load_f32(xrs, lok ? roff[i] - 4 : SKP_OOB, so, 0);
+        d[i][0][0] = skp_buf_load_f32(xrs, (edelta != 0 && roff[i] != SKP_OOB) ? roff[i] + edelta : SKP_OOB, so, 0);
         d[i][1] = f32x2{mid[0], mid[1]};
         d[i][2] = f32x2{mid[2], mid[3]};
-        d[i][0][1] = skp_buf_load_f32(xrs, rok ? roff[i] + 16 : SKP_OOB, so, 0);
     };
     auto col_pass = [&](int k) {
+        if (!GNF && k == 0) {                        // plain form: the halo pair is put together here, right before its first use
+#pragma unroll
+            for (int i = 0; i < 6; ++i) halo_row(i, d[i][0][0]);
+        }
         f32x2 v[6], t[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = d[i][k];
