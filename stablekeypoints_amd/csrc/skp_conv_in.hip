@@ -8,13 +8,14 @@
 //   packed fma), two accumulators per lane, one 8-byte store per channel -> every wave writes 512 contiguous bytes.
 // NCHW in and out, bias folded in.
 #include "skp_common.h"
+#include <algorithm>
 
 namespace {
 
 template <int CI>
 __global__ __launch_bounds__(256) void skp_conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int Co, int H,
-                                                          int W) {
+                                                          int W, int co_per) {
     const int W2 = W >> 1;
     const int pi = blockIdx.x * 256 + threadIdx.x;
     if (pi >= H * W2) return;
@@ -38,8 +39,11 @@ __global__ __launch_bounds__(256) void skp_conv_in_kernel(const float* __restric
             p[ci][r][2] = f32x2{mid[1], rt};
         }
     float* yb = y + (size_t)b * Co * plane + (size_t)yy * W + x0;
+    // blockIdx.z = slice of `co_per` output channels (small images: the pixel grid alone leaves most CUs idle and a thread would
+    // walk all Cout channels serially -- the UNet's conv_in at 64^2 was 64 workgroups x 320 channels: 262 us for a 42 MB write)
+    const int co_begin = blockIdx.z * co_per, co_end = min(Co, co_begin + co_per);
 #pragma unroll 2
-    for (int co = 0; co < Co; ++co) {
+    for (int co = co_begin; co < co_end; ++co) {
         const float* wc = w + (size_t)co * (CI * 9);            // uniform: scalar loads
         const float bv = bias ? bias[co] : 0.f;
         f32x2 acc = {bv, bv};
@@ -62,10 +66,15 @@ extern "C" int skp_conv3x3_small_f32(const void* x, const void* w, const void* b
                                      int W, void* stream) {
     if (!x || !w || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return SKP_E_BADARG;
     if (Cin > 4 || (W & 1) || B > 65535 || (long)H * W / 2 > (1L << 30)) return SKP_E_RANGE;
-    dim3 grid((unsigned)(((long)H * (W / 2) + 255) / 256), B), block(256);
+    const long wgs = (((long)H * (W / 2) + 255) / 256) * B;
+    int nz = 1;                                               // channel slices: >= ~1024 workgroups, >= 16 channels each
+    if (wgs < 1024) nz = (int)std::min<long>((Cout + 15) / 16, (1024 + wgs - 1) / wgs);
+    const int co_per = (Cout + nz - 1) / nz;
+    nz = (Cout + co_per - 1) / co_per;
+    dim3 grid((unsigned)(((long)H * (W / 2) + 255) / 256), B, nz), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define SKP_CIN(CI) \
-    hipLaunchKernelGGL(skp_conv_in_kernel<CI>, grid, block, 0, st, (const float*)x, (const float*)w, (const float*)bias, (float*)y, Cout, H, W)
+    hipLaunchKernelGGL(skp_conv_in_kernel<CI>, grid, block, 0, st, (const float*)x, (const float*)w, (const float*)bias, (float*)y, Cout, H, W, co_per)
     switch (Cin) {
         case 1: SKP_CIN(1); break;
         case 2: SKP_CIN(2); break;
