@@ -168,3 +168,30 @@ def test_graphed_step_replays_the_eager_step():
         for _ in range(3):
             g2(images2)
     assert g2.state[2] == "eager" and sum("stay on eager" in str(x.message) for x in w) == 1
+
+
+def test_vae_tail_composed_convolution_vs_module():
+    """`AutoencoderKL.encode` on the fused path: `quant_conv(conv_out(silu(GroupNorm(h))))` as ONE Winograd convolution with the
+    composed, zero-padded filter (ldm/fused.py: _vae_encode) against the module's own forward in fp64 on the same weights: posterior
+    mean and log-variance; the composition follows the weights' versions."""
+    import copy
+    from stablekeypoints_amd.ldm.fused import fuse_norms
+    from stablekeypoints_amd.ldm.vae import AutoencoderKL
+    torch.manual_seed(3)
+    ref = AutoencoderKL(block_out_channels=(32, 64, 64, 64)).eval()
+    for p_ in ref.parameters():
+        p_.requires_grad_(False)
+    with torch.no_grad():
+        ref.quant_conv.weight.normal_(0, 0.5); ref.quant_conv.bias.normal_(0, 0.5); ref.encoder.conv_out.bias.normal_(0, 0.5)
+    gpu = copy.deepcopy(ref).cuda()
+    assert fuse_norms(gpu) > 0 and "encode" in gpu.__dict__
+    x = torch.rand(2, 3, 128, 128) * 2 - 1
+    with torch.no_grad():
+        want = ref.double().encode(x.double())["latent_dist"]
+        got = gpu.encode(x.cuda())["latent_dist"]
+        assert "_skp_tail" in gpu.__dict__, "the composed tail was not taken"
+        for a, b in ((got.mean, want.mean), (got.logvar, want.logvar)):
+            torch.testing.assert_close(a.double().cpu(), b, rtol=1e-4, atol=2e-5 * b.abs().max().item())
+        gpu.quant_conv.bias.add_(1.0)                                        # version bump: the composition must follow
+        got2 = gpu.encode(x.cuda())["latent_dist"]
+        torch.testing.assert_close(got2.mean, got.mean + 1.0, rtol=1e-5, atol=1e-5)
