@@ -366,6 +366,12 @@ int skp_conv3x3_s2_ws_f32(const void* x, const void* U, const void* bias, void* 
  * Limits: Cin <= 4, W even, B <= 65535, else SKP_E_RANGE. */
 int skp_conv3x3_small_f32(const void* x, const void* w, const void* bias, void* y, int B, int Cin, int Cout, int H, int W,
                           void* stream);
+/* ... that also leaves the block statistics of its output behind for the GroupNorm that follows (the VAE's conv_in: Cin == 3,
+ * Cout <= 256, H * W % 512 == 0): stats [B][Cout][blocks][2] = {mean, sum (y - mean)^2} per block of 512 consecutive pixels,
+ * blocks = skp_conv3x3_small_stats_blocks() (0: not served). */
+int skp_conv3x3_small_stats_blocks(int B, int Cin, int Cout, int H, int W);
+int skp_conv3x3_small_stats_f32(const void* x, const void* w, const void* bias, void* y, float* stats, int B, int Cin, int Cout,
+                                int H, int W, void* stream);
 
 /* GEGLU of the transformer feed-forward (diffusers attention.GEGLU [third party], inside the hooked UNet forward):
  *   y[r, c] = p[r, c] * gelu(p[r, inner + c])    p: [rows, 2*inner], y: [rows, inner], exact (erf) gelu, inner % 4 == 0

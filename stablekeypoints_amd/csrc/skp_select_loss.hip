@@ -438,7 +438,7 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 37; }
+extern "C" int skp_abi_version(void) { return 38; }
 
 // ---- developer overrides (include/skp.h: skp_tune_set) ----
 static int g_tune[SKP_TUNE_COUNT] = {0};

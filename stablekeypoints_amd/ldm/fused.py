@@ -173,7 +173,8 @@ def _vae_attention_forward(m: AttentionBlock):
 
 def _conv_forward(m: torch.nn.Conv2d):
     def forward(x):
-        return ops.conv3x3_auto(x, m.weight, m.bias)
+        # (<= 4 input channels = a conv_in: its consumer is a ResnetBlock2D's first GroupNorm, which takes block statistics)
+        return ops.conv3x3_auto(x, m.weight, m.bias, want_stats=m.weight.shape[1] <= 4)
     return forward
 
 

@@ -1120,7 +1120,7 @@ def conv3x3_auto(x, weight, bias=None, residual=None, want_stats=False):
         return Conv3x3Fn.apply(x, weight, bias, residual)
     if (frozen and residual is None and x.is_cuda and x.dtype == torch.float32 and CONV3X3_MODE != "lib"
             and weight.shape[1] <= 4 and x.shape[3] % 2 == 0 and not (torch.is_grad_enabled() and x.requires_grad)):
-        return conv3x3_small(x, weight, bias)                  # conv_in layers: output-bandwidth bound, own VALU kernel
+        return conv3x3_small(x, weight, bias, want_stats=want_stats)   # conv_in layers: output-bandwidth bound, own VALU kernel
     if residual is None:
         return torch.nn.functional.conv2d(x, weight, bias, padding=1)
     y = torch.nn.functional.conv2d(x, weight, None, padding=1)
@@ -1200,12 +1200,21 @@ def conv3x3_gn_silu(x, norm: torch.nn.GroupNorm, weight, off=None, bias=None, re
     return y
 
 
-def conv3x3_small(x, weight, bias=None):
-    """3x3 / stride 1 / padding 1 convolution with <= 4 input channels (the conv_in layers), forward only."""
+def conv3x3_small(x, weight, bias=None, want_stats=False):
+    """3x3 / stride 1 / padding 1 convolution with <= 4 input channels (the conv_in layers), forward only.  `want_stats`: where the
+    kernel serves it (the VAE's 3 -> 128 at image resolution) the output carries its block statistics for the GroupNorm that
+    follows (`y._skp_blocks`, consumed by group_norm_silu / conv3x3_gn_silu): no separate pass over the 1 GB activation."""
     x, w = _dev(x.detach(), "x"), _dev(weight.detach(), "weight")
     B, ci, H, W = x.shape
     y = torch.empty(B, w.shape[0], H, W, device=x.device, dtype=torch.float32)
     bb = _dev(bias.detach(), "bias") if bias is not None else None
+    nblk = int(N.lib().skp_conv3x3_small_stats_blocks(B, ci, w.shape[0], H, W)) if (want_stats and GN_FUSED_STATS) else 0
+    if nblk:
+        stats = torch.empty(B, w.shape[0], nblk, 2, device=x.device, dtype=torch.float32)
+        N.check(N.lib().skp_conv3x3_small_stats_f32(x.data_ptr(), w.data_ptr(), bb.data_ptr() if bb is not None else None, y.data_ptr(),
+                                                    stats.data_ptr(), B, ci, w.shape[0], H, W, _stream()), "skp_conv3x3_small_stats_f32")
+        y._skp_blocks = (stats, nblk, 512)
+        return y
     N.check(N.lib().skp_conv3x3_small_f32(x.data_ptr(), w.data_ptr(), bb.data_ptr() if bb is not None else None, y.data_ptr(),
                                           B, ci, w.shape[0], H, W, _stream()), "skp_conv3x3_small_f32")
     return y

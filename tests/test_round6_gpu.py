@@ -195,3 +195,35 @@ def test_vae_tail_composed_convolution_vs_module():
         gpu.quant_conv.bias.add_(1.0)                                        # version bump: the composition must follow
         got2 = gpu.encode(x.cuda())["latent_dist"]
         torch.testing.assert_close(got2.mean, got.mean + 1.0, rtol=1e-5, atol=1e-5)
+
+
+def test_conv_in_block_statistics_feed_the_first_group_norm():
+    """The VAE's conv_in (3 -> 128 at image resolution) with block statistics in its epilogue (skp_conv3x3_small_stats_f32: {mean,
+    sum of squared deviations} per 512 consecutive pixels, sums about the bias, DPP wave reduction): the output is bit-identical
+    to the plain launch, the block moments match torch, and the GroupNorm that consumes them (folded into the next convolution's
+    patch load) gives what the statistics pass over the activation gives."""
+    from stablekeypoints_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, co, H, W = 4, 128, 512, 512
+    x = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).cuda()
+    w = (torch.randn(co, 3, 3, 3, generator=g) * 0.3).cuda()
+    b = (torch.randn(co, generator=g) * 3.0).cuda()                  # means far from zero: the pivot matters
+    assert ops.N.lib().skp_conv3x3_small_stats_blocks(B, 3, co, H, W) == H * W // 512
+    assert ops.N.lib().skp_conv3x3_small_stats_blocks(1, 3, co, 64, 64) == 0 and ops.N.lib().skp_conv3x3_small_stats_blocks(B, 4, co, H, W) == 0
+    y0 = ops.conv3x3_small(x, w, b)
+    y = ops.conv3x3_small(x, w, b, want_stats=True)
+    assert torch.equal(y, y0) and getattr(y, "_skp_blocks", None) is not None
+    stats, nblk, pix = y._skp_blocks
+    assert (nblk, pix) == (H * W // 512, 512) and stats.shape == (B, co, nblk, 2)
+    blk = y.double().reshape(B, co, nblk, 512)
+    torch.testing.assert_close(stats[..., 0].double(), blk.mean(-1), rtol=1e-5, atol=1e-5)
+    m2 = ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1)
+    torch.testing.assert_close(stats[..., 1].double(), m2, rtol=2e-4, atol=1e-3)
+    norm = torch.nn.GroupNorm(32, co, eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.normal_(1.0, 0.2, generator=None); norm.bias.normal_(0.0, 0.2)
+        a = ops.group_norm_silu(y, norm)                               # statistics from the blocks
+        b_ = ops.group_norm_silu(y0, norm)                             # statistics by their own pass
+        ref = torch.nn.functional.silu(torch.nn.functional.group_norm(y0.double(), 32, norm.weight.double(), norm.bias.double(), 1e-6))
+    torch.testing.assert_close(a.double(), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a, b_, rtol=1e-4, atol=1e-5)
