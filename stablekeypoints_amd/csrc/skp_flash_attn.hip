@@ -472,12 +472,18 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
                                                                    const float* __restrict__ v, const float* __restrict__ out,
                                                                    const float* __restrict__ dout, const float* __restrict__ lse,
                                                                    float* __restrict__ dq, float* __restrict__ Dbuf, int H, int N,
-                                                                   int Nk, int kvb, float scale, int ldg) {
+                                                                   int Nk, int kvb, float scale, int ldg, int nsplit,
+                                                                   float* __restrict__ part) {
     using F = FA2<D>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y, C = H * D;
-    const int nbase = blockIdx.x * (64 * NQT) + wave * (16 * NQT);
+    // nsplit > 1 (few workgroups): blockIdx.x = query block + blocks * split; a split walks its range of key tiles and leaves a
+    // partial dQ in `part` [split][B][N][C] (summed in fixed order by skp_fa2_split_reduce_kernel)
+    const int nqb = gridDim.x / nsplit, split = blockIdx.x / nqb;
+    const int kper = ((Nk + F::KT - 1) / F::KT + nsplit - 1) / nsplit * F::KT;
+    const int k_lo = split * kper, k_hi = min(Nk, k_lo + kper);
+    const int nbase = (blockIdx.x - split * nqb) * (64 * NQT) + wave * (16 * NQT);
     const size_t hoff = (size_t)(kvb ? b : 0) * Nk * C + (size_t)h * D;
     const float* kg = k + hoff;
     const float* vg = v + hoff;
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
         dsum[nt] = fa2_sum4(ds);                                // rowsum(dO * O) of query n
         const size_t si = ((size_t)b * H + h) * N + nc;
         lse2[nt] = lse[si] * SKP_LOG2E;
-        if (n < N && g == 0) Dbuf[si] = dsum[nt];
+        if (n < N && g == 0 && split == 0) Dbuf[si] = dsum[nt];
     }
     f32x4 dqa[F::CT][NQT];
 #pragma unroll
@@ -514,17 +520,17 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
     FA2Stage<D> stg;
     if (PRE) stg.init(C, tid);
     f32x4 kr[F::U], vr[F::U];
-    fa2_stage_in<D, PRE>(kr, kg, C, 0, Nk, stg, tid);
-    fa2_stage_in<D, PRE>(vr, vg, C, 0, Nk, stg, tid);
+    fa2_stage_in<D, PRE>(kr, kg, C, k_lo, Nk, stg, tid);
+    fa2_stage_in<D, PRE>(vr, vg, C, k_lo, Nk, stg, tid);
     fa2_stage_out<D, PRE>(smem, kr, stg, tid);
     fa2_stage_out<D, PRE>(smem + F::TILE, vr, stg, tid);
     __syncthreads();
 
     int cur = 0;
-    for (int kt0 = 0; kt0 < Nk; kt0 += F::KT) {
+    for (int kt0 = k_lo; kt0 < k_hi; kt0 += F::KT) {
         const float* Ks = smem + cur * 2 * F::TILE;
         const float* Vs = Ks + F::TILE;
-        const bool more = kt0 + F::KT < Nk;
+        const bool more = kt0 + F::KT < k_hi;
         if (more) {
             fa2_stage_in<D, PRE>(kr, kg, C, kt0 + F::KT, Nk, stg, tid);
             fa2_stage_in<D, PRE>(vr, vg, C, kt0 + F::KT, Nk, stg, tid);
@@ -567,7 +573,8 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dq_kernel(const float* 
     for (int nt = 0; nt < NQT; ++nt) {
         const int n = nrow[nt];
         if (n < N) {
-            float* drow = dq + ((size_t)b * N + n) * ldg + h * D;      // ldg: row stride of the gradient outputs
+            float* drow = nsplit > 1 ? part + (((size_t)split * gridDim.z + b) * N + n) * C + h * D
+                                     : dq + ((size_t)b * N + n) * ldg + h * D;      // ldg: row stride of the gradient outputs
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
@@ -583,13 +590,19 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
                                                                     const float* __restrict__ v, const float* __restrict__ dout,
                                                                     const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                     float* __restrict__ dk, float* __restrict__ dv, int H, int N,
-                                                                    int Nk, int kvb, float scale, int ldg) {
+                                                                    int Nk, int kvb, float scale, int ldg, int nsplit,
+                                                                    float* __restrict__ part) {
     using F = FA2<D>;
     constexpr int BUF = 2 * F::TILE + 2 * F::KT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.z, h = blockIdx.y, C = H * D;
-    const int tbase = blockIdx.x * (64 * NTT) + wave * (16 * NTT);
+    // nsplit > 1: blockIdx.x = key block + blocks * split; a split walks its range of query tiles; partial dK | dV in `part`
+    // [split][{dK, dV}][B][Nk][C]
+    const int nkb = gridDim.x / nsplit, split = blockIdx.x / nkb;
+    const int qper = ((N + F::KT - 1) / F::KT + nsplit - 1) / nsplit * F::KT;
+    const int q_lo = split * qper, q_hi = min(N, q_lo + qper);
+    const int tbase = (blockIdx.x - split * nkb) * (64 * NTT) + wave * (16 * NTT);
     const size_t hoff = (size_t)b * N * C + (size_t)h * D;
     const float* qg = q + hoff;
     const float* dog = dout + hoff;
@@ -625,20 +638,20 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
     FA2Stage<D> stg;
     if (PRE) stg.init(C, tid);
     f32x4 qr[F::U], dr[F::U];
-    float st = fetch_stats(0);
-    fa2_stage_in<D, PRE>(qr, qg, C, 0, N, stg, tid);
-    fa2_stage_in<D, PRE>(dr, dog, C, 0, N, stg, tid);
+    float st = fetch_stats(q_lo);
+    fa2_stage_in<D, PRE>(qr, qg, C, q_lo, N, stg, tid);
+    fa2_stage_in<D, PRE>(dr, dog, C, q_lo, N, stg, tid);
     fa2_stage_out<D, PRE>(smem, qr, stg, tid);
     fa2_stage_out<D, PRE>(smem + F::TILE, dr, stg, tid);
     if (tid < 2 * F::KT) smem[2 * F::TILE + tid] = st;
     __syncthreads();
 
     int cur = 0;
-    for (int q0 = 0; q0 < N; q0 += F::KT) {
+    for (int q0 = q_lo; q0 < q_hi; q0 += F::KT) {
         const float* Qs = smem + cur * BUF;
         const float* dOs = Qs + F::TILE;
         const float* Ls = dOs + F::TILE;                        // lse2[KT] | D[KT]
-        const bool more = q0 + F::KT < N;
+        const bool more = q0 + F::KT < q_hi;
         if (more) {
             st = fetch_stats(q0 + F::KT);
             fa2_stage_in<D, PRE>(qr, qg, C, q0 + F::KT, N, stg, tid);
@@ -680,17 +693,36 @@ __global__ __launch_bounds__(256, MINW) void skp_fa2_bwd_dkv_kernel(const float*
     for (int tt = 0; tt < NTT; ++tt) {
         const int t = trow[tt];
         if (t < Nk) {
-            const size_t ro = ((size_t)b * Nk + t) * ldg + h * D;
+            const size_t rows = (size_t)gridDim.z * Nk;
+            float* dkr = nsplit > 1 ? part + (((size_t)split * 2) * rows + (size_t)b * Nk + t) * C + h * D
+                                    : dk + ((size_t)b * Nk + t) * ldg + h * D;
+            float* dvr = nsplit > 1 ? dkr + rows * C : dv + ((size_t)b * Nk + t) * ldg + h * D;
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
                 if (c0 < D) {
-                    *(f32x4*)(dk + ro + c0) = dka[ct][tt] * scale;
-                    *(f32x4*)(dv + ro + c0) = dva[ct][tt];
+                    *(f32x4*)(dkr + c0) = dka[ct][tt] * scale;
+                    *(f32x4*)(dvr + c0) = dva[ct][tt];
                 }
             }
         }
     }
+}
+
+// out[row][0..C) (row stride ldg) = sum_s part[s * sstride + row * C ...]   (fixed order; blockIdx.y = which of up to three tensors)
+struct FA2SplitReduce {
+    const float* part[3];
+    float* out[3];
+    long n4[3];          // float4 per tensor
+    long sstride[3];     // floats between consecutive splits of a tensor
+};
+__global__ __launch_bounds__(256) void skp_fa2_split_reduce_kernel(FA2SplitReduce a, int nsplit, int c4, int ldg4) {
+    const int z = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n4[z]) return;
+    f32x4 acc = ((const f32x4*)a.part[z])[i];
+    for (int s = 1; s < nsplit; ++s) acc += ((const f32x4*)(a.part[z] + (size_t)s * a.sstride[z]))[i];
+    ((f32x4*)a.out[z])[(i / c4) * ldg4 + (i % c4)] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -744,7 +776,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
                                                                    const float* __restrict__ v, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqp, float* __restrict__ dk,
-                                                                   float* __restrict__ dv, int H, int N, int Nk, float scale, int ldg) {
+                                                                   float* __restrict__ dv, int H, int N, int Nk, float scale, int ldg,
+                                                                   int nsplit, float* __restrict__ kvpart) {
     using F = FA2<D>;
     using X = FA2F<D, OVL, NQ>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -756,7 +789,13 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
     constexpr int TT = 8 / NW, KW = 16 * TT, NTH = 64 * NW;    // key tiles per wave, keys per wave, threads
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
     const int stid = tid < 256 ? tid : (1 << 24);              // tile staging is dealt to the first 256 threads
-    const int kb = blockIdx.x, b = blockIdx.z, h = blockIdx.y, C = H * D;
+    // nsplit > 1 (fewer key blocks than CUs): blockIdx.x = key block + blocks * split; a split walks its range of query tiles and
+    // leaves partial dK | dV in `kvpart` [split][{dK, dV}][B][Nk][C] (skp_fa2_split_reduce_kernel); the dQ partials are per
+    // (key block, query tile) either way
+    const int nkbx = gridDim.x / nsplit, split = blockIdx.x / nkbx;
+    const int kb = blockIdx.x - split * nkbx, b = blockIdx.z, h = blockIdx.y, C = H * D;
+    const int qper = ((N + X::QT - 1) / X::QT + nsplit - 1) / nsplit * X::QT;
+    const int q_lo = split * qper, q_hi = min(N, q_lo + qper);
     const int t0 = kb * X::KB;
     const size_t hoff = (size_t)b * N * C + (size_t)h * D;     // self-attention: q, k, v, dout share [B, N, C]
     const float* qg = q + hoff;
@@ -801,9 +840,9 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
     FA2Stage<D> stg;
     stg.init(C, stid, X::QT);
     f32x4 qr[F::U], dr[F::U];
-    float st = fetch_stats(0);
-    fa2_fetch_tile<D>(qr, qg, C, 0, N, stg, stid);
-    fa2_fetch_tile<D>(dr, dog, C, 0, N, stg, stid);
+    float st = fetch_stats(q_lo);
+    fa2_fetch_tile<D>(qr, qg, C, q_lo, N, stg, stid);
+    fa2_fetch_tile<D>(dr, dog, C, q_lo, N, stg, stid);
     fa2_put<D>(Qs, qr, stg);
     fa2_put<D>(dOs, dr, stg);
     if (tid < 128) Ls[tid] = st;
@@ -811,8 +850,8 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
 
     const size_t pstride = (size_t)gridDim.z * N * C;          // floats per key-block partial of dQ
     float* dqb = dqp + (size_t)kb * pstride + hoff;
-    for (int q0 = 0; q0 < N; q0 += X::QT) {
-        const bool more = q0 + X::QT < N;
+    for (int q0 = q_lo; q0 < q_hi; q0 += X::QT) {
+        const bool more = q0 + X::QT < q_hi;
         if (!OVL && more) {                                     // next query tile: in flight under this tile's MFMAs
             st = fetch_stats(q0 + X::QT);
             fa2_fetch_tile<D>(qr, qg, C, q0 + X::QT, N, stg, stid);
@@ -923,13 +962,16 @@ __global__ __launch_bounds__(64 * NW, MINB) void skp_fa2_bwd_fused_kernel(const 
     for (int tt = 0; tt < TT; ++tt) {
         const int t = trow[tt];
         if (t < Nk) {
-            const size_t ro = ((size_t)b * Nk + t) * ldg + h * D;
+            const size_t rows = (size_t)gridDim.z * Nk;
+            float* dkr = nsplit > 1 ? kvpart + (((size_t)split * 2) * rows + (size_t)b * Nk + t) * C + h * D
+                                    : dk + ((size_t)b * Nk + t) * ldg + h * D;
+            float* dvr = nsplit > 1 ? dkr + rows * C : dv + ((size_t)b * Nk + t) * ldg + h * D;
 #pragma unroll
             for (int ct = 0; ct < F::CT; ++ct) {
                 const int c0 = 16 * ct + 4 * g;
                 if (c0 < D) {
-                    *(f32x4*)(dk + ro + c0) = dka[ct][tt] * scale;
-                    *(f32x4*)(dv + ro + c0) = dva[ct][tt];
+                    *(f32x4*)(dkr + c0) = dka[ct][tt] * scale;
+                    *(f32x4*)(dvr + c0) = dva[ct][tt];
                 }
             }
         }
@@ -1009,6 +1051,22 @@ int skp_fa2_fwd(const float* q, const float* k, const float* v, float* out, floa
 #undef FA2_FWD
 }
 
+// Range splits of the backward at few workgroups (1 image per rank: the 16^2 layers are 64 workgroups of the two-kernel form,
+// the 32^2 layers 128 of the fused one -- a quarter / half of the CUs).  Each split must own at least two tiles.
+static int fa2_two_kernel_splits(int B, int H, int N, int Nk, int d) {
+    if (d != 160) return 1;                                  // (64 queries / keys per workgroup, 32-row tiles at this head size)
+    const long wgs = (long)((std::max(N, Nk) + 63) / 64) * H * B;
+    const int tiles = std::min(N, Nk) / 32;
+    int ns = 1;
+    while (ns < 4 && wgs * ns * 2 <= 256 && tiles / (ns * 2) >= 2) ns *= 2;
+    return ns;
+}
+static int fa2_fused_splits(int B, int H, int N, int Nk, int d) {
+    if (d != 80) return 1;                                   // one 120 KB workgroup per CU: a split helps only below 256 of them
+    const long wgs = (long)((Nk + 127) / 128) * H * B;
+    return (wgs * 2 <= 256 && N >= 256) ? 2 : 1;
+}
+
 template <int D, int NQ, int MINWQ, int NT, int MINWT, bool PRE>
 static int fa2_launch_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
                           const float* lse, float* dq, float* dk, float* dv, float* ws, int B, int H, int N, int Nk, int kvb,
@@ -1024,12 +1082,25 @@ static int fa2_launch_bwd(const float* q, const float* k, const float* v, const 
         attr = true;
     }
     dim3 block(256);
-    hipLaunchKernelGGL((skp_fa2_bwd_dq_kernel<D, NQ, MINWQ, PRE>), dim3((N + 64 * NQ - 1) / (64 * NQ), H, B), block, lds_q, st,
-                       q, k, v, out, dout, lse, dq, ws, H, N, Nk, kvb, scale, ldg);
+    const int nqb = (N + 64 * NQ - 1) / (64 * NQ), nkb = (Nk + 64 * NT - 1) / (64 * NT);
+    const int ns = fa2_two_kernel_splits(B, H, N, Nk, D);
+    float* part = ws + (size_t)B * H * N;                   // [ns][B][N][C] dQ | [ns][2][B][Nk][C] dK, dV
+    float* kvpart = part + (size_t)ns * B * N * H * D;
+    hipLaunchKernelGGL((skp_fa2_bwd_dq_kernel<D, NQ, MINWQ, PRE>), dim3(nqb * ns, H, B), block, lds_q, st,
+                       q, k, v, out, dout, lse, dq, ws, H, N, Nk, kvb, scale, ldg, ns, part);
     int rc = skp_launch_status();
     if (rc) return rc;
-    hipLaunchKernelGGL((skp_fa2_bwd_dkv_kernel<D, NT, MINWT, PRE>), dim3((Nk + 64 * NT - 1) / (64 * NT), H, B), block, lds_kv, st,
-                       q, k, v, dout, lse, ws, dk, dv, H, N, Nk, kvb, scale, ldg);
+    hipLaunchKernelGGL((skp_fa2_bwd_dkv_kernel<D, NT, MINWT, PRE>), dim3(nkb * ns, H, B), block, lds_kv, st,
+                       q, k, v, dout, lse, ws, dk, dv, H, N, Nk, kvb, scale, ldg, ns, kvpart);
+    rc = skp_launch_status();
+    if (rc || ns == 1) return rc;
+    const long C = (long)H * D, nq4 = (long)B * N * C / 4, nk4 = (long)B * Nk * C / 4;
+    FA2SplitReduce a;
+    a.part[0] = part; a.out[0] = dq; a.n4[0] = nq4; a.sstride[0] = (long)B * N * C;
+    a.part[1] = kvpart; a.out[1] = dk; a.n4[1] = nk4; a.sstride[1] = 2 * (long)B * Nk * C;
+    a.part[2] = kvpart + (size_t)B * Nk * C; a.out[2] = dv; a.n4[2] = nk4; a.sstride[2] = 2 * (long)B * Nk * C;
+    hipLaunchKernelGGL(skp_fa2_split_reduce_kernel, dim3((unsigned)((std::max(nq4, nk4) + 255) / 256), 3), dim3(256), 0, st, a, ns,
+                       (int)(C / 4), ldg / 4);
     return skp_launch_status();
 }
 
@@ -1048,7 +1119,14 @@ static bool fa2_fused_ok(int Bk, int B, int H, int N, int Nk, int d) {
 // bytes of scratch the backward needs: D = rowsum(dO * O) [B,H,N], plus the per-key-block dQ partials of the fused form
 int64_t skp_fa2_bwd_workspace(int B, int Bk, int H, int N, int Nk, int d) {
     int64_t fl = (int64_t)B * H * N;
-    if (fa2_fused_ok(Bk, B, H, N, Nk, d)) fl += (int64_t)((Nk + 127) / 128) * B * N * H * d;
+    if (fa2_fused_ok(Bk, B, H, N, Nk, d)) {
+        fl += (int64_t)((Nk + 127) / 128) * B * N * H * d;
+        const int ns = fa2_fused_splits(B, H, N, Nk, d);
+        if (ns > 1) fl += (int64_t)ns * 2 * B * Nk * H * d;
+    } else {
+        const int ns = fa2_two_kernel_splits(B, H, N, Nk, d);
+        if (ns > 1) fl += (int64_t)ns * B * ((int64_t)N + 2 * Nk) * H * d;
+    }
     return fl * (int64_t)sizeof(float);
 }
 
@@ -1071,13 +1149,23 @@ static int fa2_launch_bwd_fused(const float* q, const float* k, const float* v, 
     int rc = skp_launch_status();
     if (rc) return rc;
     const int nkb = (Nk + X::KB - 1) / X::KB;
-    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ, NW>), dim3(nkb, H, B), dim3(64 * NW), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
-                       N, Nk, scale, ldg);
+    const int ns = fa2_fused_splits(B, H, N, Nk, D);
+    float* kvpart = part + (size_t)nkb * B * N * H * D;
+    hipLaunchKernelGGL((skp_fa2_bwd_fused_kernel<D, MINB, OVL, NQ, NW>), dim3(nkb * ns, H, B), dim3(64 * NW), lds, st, q, k, v, dout, lse, Dbuf, part, dk, dv, H,
+                       N, Nk, scale, ldg, ns, kvpart);
     rc = skp_launch_status();
     if (rc) return rc;
     const long n4 = (long)B * N * H * D / 4;
     hipLaunchKernelGGL(skp_fa2_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, dq, n4,
                        (long)B * N * H * D, nkb, scale, H * D / 4, ldg / 4);
+    rc = skp_launch_status();
+    if (rc || ns == 1) return rc;
+    const long nk4 = (long)B * Nk * H * D / 4;
+    FA2SplitReduce a;
+    a.part[0] = kvpart; a.out[0] = dk; a.n4[0] = nk4; a.sstride[0] = 2 * (long)B * Nk * H * D;
+    a.part[1] = kvpart + (size_t)B * Nk * H * D; a.out[1] = dv; a.n4[1] = nk4; a.sstride[1] = 2 * (long)B * Nk * H * D;
+    a.part[2] = nullptr; a.out[2] = nullptr; a.n4[2] = 0; a.sstride[2] = 0;
+    hipLaunchKernelGGL(skp_fa2_split_reduce_kernel, dim3((unsigned)((nk4 + 255) / 256), 2), dim3(256), 0, st, a, ns, H * D / 4, ldg / 4);
     return skp_launch_status();
 }
 

@@ -340,7 +340,10 @@ def test_fused_group_norm_silu_fwd_bwd(ops, N, C, G, H, W, silu, with_off):
 
 
 @pytest.mark.parametrize("B,N,H,d", [(2, 1024, 8, 80), (1, 4096, 8, 40), (2, 200, 4, 8), (1, 256, 8, 160), (3, 64, 2, 16),
-                                     (1, 130, 4, 40), (1, 576, 5, 64), (2, 100, 2, 32), (2, 1100, 2, 40), (1, 1281, 3, 40), (1, 1100, 2, 64), (2, 1024, 3, 64)])
+                                     (1, 130, 4, 40), (1, 576, 5, 64), (2, 100, 2, 32), (2, 1100, 2, 40), (1, 1281, 3, 40), (1, 1100, 2, 64), (2, 1024, 3, 64),
+                                     # few workgroups: range splits of the backward (partials + fixed-order sum): four / two splits of the
+                                     # two-kernel form, a ragged last tile, a split that owns no tile, the fused form's two query halves
+                                     (2, 256, 8, 160), (4, 256, 8, 160), (3, 200, 2, 160), (2, 288, 8, 160), (1, 1100, 8, 80)])
 def test_flash_self_attention_fwd_bwd_vs_fp64(ops, B, N, H, d):
     """Flash-style fp32-MFMA self-attention against the materialised reference formulation in fp64."""
     g = torch.Generator().manual_seed(13)
