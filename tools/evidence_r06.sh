@@ -5,6 +5,9 @@
 #   pmc_map.json               counter passes over tools/map_bench.py (VALU / LDS counters of the north-star kernels)
 R=$GRAFT_REPO_ROOT; TAG=${1:-final}; O=$R/gpurun_out/r06/$TAG; mkdir -p $O; cd $R
 python bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log > $O/bench_default.json; echo default rc=$?
+# boxes differ by ~5 % (sustained clock): with MAXMS set, a box slower than that is not worth the rest of the run
+if [ -n "$MAXMS" ]; then python -c "
+import json,sys; d=json.load(open('$O/bench_default.json')); print('default ms/step', d['ms_per_step']); sys.exit(0 if d['ms_per_step'] <= float('$MAXMS') else 3)" || exit 3; fi
 cd /tmp; export TMPDIR=/tmp
 for ipr in 4 1; do
   sfx=""; [ $ipr = 1 ] && sfx="_ipr1"
