@@ -47,7 +47,8 @@ int skp_abi_version(void);
 /* Developer overrides of launch plans, for tests/ and tools/ only (the product path never calls them; the library reads no
  * environment variables).  Keys: "wino_split" (force the K split of the F(4x4,3x3) launches), "wino_raw_max_tiles" (widen the
  * raw-filter form's gate), "map_bands" (band count of the token-major map backward), "fa2_two_kernel_bwd" (1: the two-kernel
- * flash backward at the fused form's shapes), "gn_fold_max_cout".  value 0 = the library's own choice.  Process-global, not
+ * flash backward at the fused form's shapes), "gn_fold_max_cout", "cross_attn_ts" (1: the 128-query
+ * cross-attention kernels where the token-split form would run).  value 0 = the library's own choice.  Process-global, not
  * thread-safe.  Returns 0 / the value, SKP_E_RANGE for an unknown key. */
 int skp_tune_set(const char* key, int value);
 int skp_tune_get(const char* key);

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: libskp_hip.so has 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKP_LIB_PATH: another BUILD of the same library (same-box A/B of two kernel versions, tools/ab_build.py); never a fallback
 LIB_PATH = os.environ.get("SKP_LIB_PATH") or os.path.join(_HERE, "csrc", "libskp_hip.so")
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 

@@ -13,7 +13,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Developer overrides of launch plans (skp_tune_set in include/skp.h): tests and tools/ only, 0 = the library's own choice.
 // The library reads no environment variables.
-enum { SKP_TUNE_WINO_SPLIT = 0, SKP_TUNE_WINO_RAW_MAX_TILES, SKP_TUNE_MAP_BANDS, SKP_TUNE_FA2_TWO_KERNEL_BWD, SKP_TUNE_GN_FOLD_MAX_COUT,
+enum { SKP_TUNE_WINO_SPLIT = 0, SKP_TUNE_WINO_RAW_MAX_TILES, SKP_TUNE_MAP_BANDS, SKP_TUNE_FA2_TWO_KERNEL_BWD, SKP_TUNE_GN_FOLD_MAX_COUT, SKP_TUNE_CROSS_ATTN_TS,
        SKP_TUNE_COUNT };
 int skp_tune(int key);                              // skp_select_loss.hip
 

@@ -34,13 +34,41 @@ __global__ __launch_bounds__(256) void skp_gemm_nt_kernel(GemmArgs g) {
     const int kbeg = ks * g.kchunk;
     const int K = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;     // kchunk is a multiple of 8
     int k = kbeg;
-    for (; k + 8 <= K; k += 8) {
-        const int kk = k + 4 * hi;
-        f32x4 a, b;
+    auto load8 = [&](int k8, f32x4& a, f32x4& b) {
+        const int kk = k8 + 4 * hi;
         if (AV) a = *(const f32x4*)(Ap + kk);
         else { a[0] = Ap[(int64_t)kk * g.sak]; a[1] = Ap[(int64_t)(kk + 1) * g.sak]; a[2] = Ap[(int64_t)(kk + 2) * g.sak]; a[3] = Ap[(int64_t)(kk + 3) * g.sak]; }
         if (BV) b = *(const f32x4*)(Bp + kk);
         else { b[0] = Bp[(int64_t)kk * g.sbk]; b[1] = Bp[(int64_t)(kk + 1) * g.sbk]; b[2] = Bp[(int64_t)(kk + 2) * g.sbk]; b[3] = Bp[(int64_t)(kk + 3) * g.sbk]; }
+    };
+    // 32 k per step, the NEXT step's operands requested before this step's 16 MFMAs: the contraction is a chain of L2 / HBM round
+    // trips otherwise (one per 8 k: the dK | dV reductions of the cross-attention backward, K = 256 per split, were 21-82 us launches
+    // for 10 us of traffic)
+    constexpr int U = 4;
+    if (k + 8 * U <= K) {
+        f32x4 a[U], b[U], an[U], bn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load8(k + 8 * u, a[u], b[u]);
+        for (; k + 8 * U <= K; k += 8 * U) {
+            const bool more = k + 16 * U <= K;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) load8(k + 8 * U + 8 * u, an[u], bn[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mv ? a[u][m] : 0.f, nv ? b[u][m] : 0.f, acc, 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { a[u] = an[u]; b[u] = bn[u]; }
+            }
+        }
+    }
+    for (; k + 8 <= K; k += 8) {
+        f32x4 a, b;
+        load8(k, a, b);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mv ? a[u] : 0.f, nv ? b[u] : 0.f, acc, 0, 0, 0);

@@ -438,11 +438,11 @@ extern "C" int skp_rows_axpy_f32(float* dst, const int64_t* sel, int K, int64_t 
     return skp_launch_status();
 }
 
-extern "C" int skp_abi_version(void) { return 38; }
+extern "C" int skp_abi_version(void) { return 39; }
 
 // ---- developer overrides (include/skp.h: skp_tune_set) ----
 static int g_tune[SKP_TUNE_COUNT] = {0};
-static const char* const g_tune_names[SKP_TUNE_COUNT] = {"wino_split", "wino_raw_max_tiles", "map_bands", "fa2_two_kernel_bwd", "gn_fold_max_cout"};
+static const char* const g_tune_names[SKP_TUNE_COUNT] = {"wino_split", "wino_raw_max_tiles", "map_bands", "fa2_two_kernel_bwd", "gn_fold_max_cout", "cross_attn_ts"};
 int skp_tune(int key) { return (key >= 0 && key < SKP_TUNE_COUNT) ? g_tune[key] : 0; }
 extern "C" int skp_tune_set(const char* key, int value) {
     if (!key || value < 0) return SKP_E_BADARG;

@@ -208,7 +208,10 @@ def test_sd_shape_maps_invariants(ops):
 
 @pytest.mark.parametrize("B,Bk,N,H,d,T", [(2, 1, 256, 8, 160, 77), (1, 1, 100, 4, 8, 16), (2, 2, 1024, 8, 80, 77),
                                           (1, 1, 4096, 8, 40, 100), (3, 1, 64, 2, 16, 5), (1, 1, 576, 5, 64, 77),
-                                          (2, 1, 96, 3, 32, 30)])
+                                          (2, 1, 96, 3, 32, 30),
+                                          # token-split form (small layers: a wave per 32-token tile): 8^2 layer, ragged query block
+                                          # with four tiles, two tiles, four full tiles with per-row keys
+                                          (8, 1, 64, 8, 160, 77), (2, 1, 250, 4, 160, 100), (1, 1, 96, 3, 80, 40), (3, 3, 200, 2, 80, 128)])
 def test_cross_attention_fwd_bwd_vs_fp64(ops, B, Bk, N, H, d, T):
     """Fused fp32-MFMA cross-attention (ptp_utils.py:493-506) against the reference formulation in fp64."""
     g = torch.Generator().manual_seed(11)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Cross-attention at T <= 128: the fused kernel (skp_cross_attn_*) against the flash kernels on the same inputs, per layer shape.
-    rocprofv3 --kernel-trace --stats -- python tools/cross_route_probe.py {cross|flash} [rows]     (kernel time = sum of the stats)
+    rocprofv3 --kernel-trace --stats -- python tools/cross_route_probe.py {cross|cross128|flash} [rows]     (kernel time = sum of the stats)
     python tools/cross_route_probe.py check [rows]                                                  (max differences between the two)"""
 import os
 import sys
@@ -26,7 +26,8 @@ def main():
         k = torch.randn(1, T, C, generator=g).cuda().requires_grad_(True)
         v = torch.randn(1, T, C, generator=g).cuda().requires_grad_(True)
         w = torch.randn(rows, Nq, C, generator=g).cuda()
-        fns = {"cross": ops.CrossAttnFn, "flash": ops.FlashAttnFn}
+        fns = {"cross": ops.CrossAttnFn, "cross128": ops.CrossAttnFn, "flash": ops.FlashAttnFn}
+        ops.N.tune("cross_attn_ts", 1 if which == "cross128" else 0)     # cross128: the 128-query kernels where the token-split form would run
         if which == "check":
             res = {}
             for name, fn in fns.items():
